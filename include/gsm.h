@@ -1,0 +1,154 @@
+/*
+ * gsm.h -- C ABI of the MI355X-native many-chain geostatistical MCMC sampler (libgsm_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of tylerrleee/mcmc-gpu: the large-scale-chain
+ * Metropolis step.  Every entry point names the reference interface it replaces (paths relative to
+ * the reference repository root).  The reference is pure Python, so its "FFI" for this path is a
+ * ctypes binding; INTEGRATION.md shows the stub a maintainer adds to gstatsMCMC/MCMC_gpu.py.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross the boundary.
+ *   - Every pointer marked [dev] is a DEVICE pointer (e.g. torch.Tensor.data_ptr() of a cuda tensor),
+ *     row-major, borrowed for the duration of the call (asynchronous calls: until the stream has been
+ *     synchronised).  The caller owns all state; the library owns only its handle and scratch.
+ *   - Return value 0 = ok, negative = error (GSM_E_*); gsm_last_error() gives the text.  No C++
+ *     exception crosses the ABI.  A handle is not thread-safe; distinct handles are independent.
+ *   - "stream" is a hipStream_t passed as void* (0 = the null stream).  Kernels are enqueued on it and
+ *     the call returns without synchronising unless stated.
+ *   - Grids are H rows x W columns, fp64.  Chain c's bed is beds + c*H*W.
+ *
+ * Layout of per-step records, for chain c and step s of a call with n_steps steps: index c*n_steps+s.
+ */
+#ifndef GSM_H
+#define GSM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gsm_context* gsm_handle;
+
+enum {
+  GSM_OK = 0,
+  GSM_E_ARG = -1,       /* bad argument (null pointer, non-positive size, block larger than grid ...) */
+  GSM_E_STATE = -2,     /* call order violated (e.g. run before set_static) */
+  GSM_E_HIP = -3,       /* a HIP runtime call failed */
+  GSM_E_UNSUPPORTED = -4, /* valid request this build cannot serve (dtype, block larger than the LDS tile) */
+  GSM_E_DEVICE_DATA = -5  /* a kernel found an out-of-range size index / block centre in device data */
+};
+
+enum { GSM_MODEL_GAUSSIAN = 0, GSM_MODEL_EXPONENTIAL = 1, GSM_MODEL_MATERN = 2 };
+
+/* Random-field parameters: mirrors RandField.__init__ (gstatsMCMC/MCMC.py:462-510) plus the grid
+ * resolution handed to spectral_synthesis_field (MCMC.py:176, :767). */
+typedef struct {
+  double range_min_x, range_max_x, range_min_y, range_max_y;
+  double scale_min, scale_max;
+  double nugget_max;
+  double smoothness;  /* Matern nu; ignored otherwise */
+  double resolution;
+  int32_t model;      /* GSM_MODEL_* */
+  int32_t isotropic;  /* 1: one range draw shared by x and y (MCMC.py:207) */
+} gsm_rf_params;
+
+/* Library / build identification: "gsm-hip <version> gfx950". */
+const char* gsm_version(void);
+
+/* Text of the last error on this handle (or of the last failed gsm_create when h is NULL). */
+const char* gsm_last_error(gsm_handle h);
+
+/* Create a sampler for n_chains chains on an H x W grid on HIP device `device`.
+ * dtype: 0 = fp64 state (the only one this build serves).
+ * Replaces: the per-process chain construction of lsc_run_wrapper
+ * (largeScaleChain_multiprocessing_GPU.py:126-127) -- one handle holds all chains of one GPU. */
+int gsm_create(gsm_handle* out, int32_t H, int32_t W, int32_t n_chains, int32_t dtype, int32_t device);
+int gsm_destroy(gsm_handle h);
+
+/* Static fields shared by all chains [dev, H*W each].  crf_weight may be NULL => block_type 'RF'
+ * (MCMC.py:1279-1282).  update_mask: 1 where a proposal may change the bed AND where the thickness
+ * guard and resampled_times apply (region_mask when update_in_region else grounded_ice_mask,
+ * MCMC.py:1287-1290, :1323-1328, :1349-1352).  mc_mask: 1 where the residual enters the loss
+ * (mc_region_mask, MCMC.py:1041).  The arrays are copied; the caller may free them afterwards.
+ * Replaces: chain.__init__ / set_update_region / set_loss_type / set_crf_data_weight state
+ * (MCMC.py:808-848, :849-872, :950-1018, :1124-1134). */
+int gsm_set_static(gsm_handle h, const double* surf, const double* velx, const double* vely,
+                   const double* dhdt, const double* smb, const double* crf_weight,
+                   const uint8_t* update_mask, const uint8_t* mc_mask,
+                   double resolution, double sigma_mc, void* stream);
+
+/* Proposal block table: n_sizes (bh, bw) pairs [host] and their edge masks packed back to back [dev],
+ * mask i starting at mask_offsets[i] doubles [host, n_sizes entries].  Masks are needed only by the
+ * Philox proposal generator; replay mode receives fields that already carry the mask.
+ * Replaces: RandField.set_block_sizes / set_weight_param (MCMC.py:524-566, :568-623). */
+int gsm_set_blocks(gsm_handle h, int32_t n_sizes, const int32_t* bh, const int32_t* bw,
+                   const double* edge_masks_packed, const int64_t* mask_offsets, void* stream);
+
+/* Cells (flat index row*W+col) [dev] from which Philox mode draws block centres uniformly --
+ * the cells with region_mask==1; same distribution as the rejection loop of MCMC.py:1253-1261. */
+int gsm_set_centres(gsm_handle h, const int32_t* cells, int32_t n_cells, void* stream);
+
+/* Full-grid residual and loss of every chain's current bed.
+ * loss_sum [dev, n_chains*2]: compensated (hi, lo) sum of squared residuals over mc_mask, the state
+ * carried between steps;  loss0 [dev, n_chains]: that sum / (2 sigma^2) = loss_cache[0].
+ * Replaces: MCMC.py:1189-1195 (Topography.get_mass_conservation_residual, Topography.py:592-600,
+ * and chain.loss, MCMC.py:1021-1044). */
+int gsm_init_loss(gsm_handle h, const double* beds, double* loss_sum, double* loss0, void* stream);
+
+/* Full-grid residual of chain beds [dev, n_chains*H*W] -> residual [dev, same shape].
+ * Replaces: Topography.get_mass_conservation_residual (Topography.py:592-600). */
+int gsm_residual(gsm_handle h, const double* beds, double* residual, void* stream);
+
+/* n_steps Metropolis steps per chain with caller-supplied draws ("replay" / parity mode).
+ *   size_idx [dev, n_chains*n_steps]      index into the block table
+ *   centre   [dev, n_chains*n_steps*2]    (row, col) block centre
+ *   u        [dev, n_chains*n_steps]      uniform draw of the accept test
+ *   fields   [dev]                        masked proposal fields f (bh x bw, row-major) at
+ *                                         fields + (c*n_steps+s)*field_stride doubles
+ * In/out state: beds, resampled (uint32 counts), loss_sum.  Outputs: loss [n_chains*n_steps]
+ * (loss_cache entries), accept [n_chains*n_steps] (0/1).
+ * Synchronises the stream before returning (it reports out-of-range device data as GSM_E_DEVICE_DATA).
+ * Replaces: the loop body of chain_crf.run, MCMC.py:1263-1360 (torch twin MCMC_gpu.py:385-494). */
+int gsm_run_replay(gsm_handle h, int32_t n_steps, double* beds, uint32_t* resampled, double* loss_sum,
+                   const int32_t* size_idx, const int32_t* centre, const double* u,
+                   const double* fields, int64_t field_stride,
+                   double* loss, uint8_t* accept, void* stream);
+
+/* Philox4x32-10 proposal generator: for every chain and steps step0 .. step0+n_steps-1 draws the block
+ * size, the block centre, the accept uniform and one spectral-synthesis field (already multiplied by
+ * its edge mask), into the same layout gsm_run_replay consumes.  rf_scalars (optional, may be NULL)
+ * [dev, n_chains*n_steps*4] receives (scale, nugget, range_x, range_y).
+ * Key = seeds[c] [dev, n_chains]; counters are functions of (absolute step, draw index) only, so a run
+ * split into segments reproduces the unsplit run.
+ * Replaces: RandField.get_rfblock + spectral_synthesis_field (MCMC.py:742-778, :176-254), the centre
+ * rejection loop (MCMC.py:1253-1261) and rng.random() (MCMC.py:1336). */
+int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, const uint64_t* seeds,
+                       const gsm_rf_params* rf, int32_t* size_idx, int32_t* centre, double* u,
+                       double* fields, int64_t field_stride, double* rf_scalars, void* stream);
+
+/* Philox mode end to end: batches of `batch` steps, proposals of batch k+1 generated on a second
+ * stream while batch k is stepped.  Outputs as gsm_run_replay plus blocks [dev, n_chains*n_steps*4]
+ * = (row, col, bh, bw) (blocks_cache, MCMC.py:1264).  Scratch for the proposals is owned by the handle.
+ * Synchronises the stream before returning.
+ * Replaces: chain_crf.run for a whole shard of chains (MCMC.py:1137-1443) as called from
+ * lsc_run_wrapper (largeScaleChain_multiprocessing_GPU.py:194-201). */
+int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int32_t batch, const uint64_t* seeds,
+                   const gsm_rf_params* rf, double* beds, uint32_t* resampled, double* loss_sum,
+                   double* loss, uint8_t* accept, int32_t* blocks, void* stream);
+
+/* Average duration in milliseconds of the step kernel / the proposal kernel over the launches made
+ * by the last gsm_run_philox call, measured with HIP events on the streams the kernels ran on
+ * (0 when timing was not enabled with gsm_enable_timing(h, 1)). */
+int gsm_enable_timing(gsm_handle h, int32_t on);
+int gsm_last_timing(gsm_handle h, double* step_kernel_ms, int32_t* step_launches,
+                    double* proposal_kernel_ms, int32_t* proposal_launches);
+
+/* Test hook: one Philox4x32-10 block on the host (ctr[4], key[2] -> out[4]); the device generator uses
+ * the same inline function.  Checked against the Random123 known-answer vectors. */
+int gsm_philox_selftest(const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSM_H */

@@ -1,0 +1,123 @@
+"""Build and load libgsm_hip.so (the C-ABI HIP library, include/gsm.h) through ctypes.
+
+There is no CPU fallback: if the library is missing or cannot be loaded, ``load()`` raises and every
+product entry point that needs the device fails with it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+LIB_PATH = PKG_DIR / "libgsm_hip.so"
+HEADER = PKG_DIR.parent / "include" / "gsm.h"
+SOURCES = ["gsm_api.hip", "step_kernel.hip", "proposal_kernel.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wno-unused-value", "-Wno-unused-result"]
+
+
+class GsmError(RuntimeError):
+    """Raised when a libgsm_hip call returns a negative status."""
+
+    def __init__(self, code: int, text: str):
+        super().__init__(f"libgsm_hip error {code}: {text}")
+        self.code = code
+
+
+def _stale() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    t = LIB_PATH.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES] + list(CSRC.glob("*.h")) + [HEADER]
+    return any(p.stat().st_mtime > t for p in deps if p.exists())
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile the HIP sources for gfx950 into mcmc_gpu_amd/libgsm_hip.so (in-tree)."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libgsm_hip.so")
+    cmd = [hipcc, *HIPCC_FLAGS, "-o", str(LIB_PATH), *[str(CSRC / s) for s in SOURCES]]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+def declared_symbols() -> list[str]:
+    """Function names declared in include/gsm.h."""
+    txt = HEADER.read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsm_[a-z0-9_]+)\s*\(", txt)))
+
+
+class RfParams(C.Structure):
+    """Mirror of gsm_rf_params (include/gsm.h)."""
+    _fields_ = [("range_min_x", C.c_double), ("range_max_x", C.c_double),
+                ("range_min_y", C.c_double), ("range_max_y", C.c_double),
+                ("scale_min", C.c_double), ("scale_max", C.c_double),
+                ("nugget_max", C.c_double), ("smoothness", C.c_double), ("resolution", C.c_double),
+                ("model", C.c_int32), ("isotropic", C.c_int32)]
+
+
+MODEL_IDS = {"Gaussian": 0, "Exponential": 1, "Matern": 2}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the library (once) and declare the prototypes of include/gsm.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+    # torch ships its own HIP/HSA runtime.  Import it first so that libgsm_hip's NEEDED libamdhip64.so.7
+    # resolves to the runtime torch already loaded -- two HIP runtimes in one process cannot both see the GPU.
+    import torch  # noqa: F401
+    lib = C.CDLL(str(LIB_PATH))
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    lib.gsm_version.restype = C.c_char_p
+    lib.gsm_version.argtypes = []
+    lib.gsm_last_error.restype = C.c_char_p
+    lib.gsm_last_error.argtypes = [vp]
+    lib.gsm_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32]
+    lib.gsm_destroy.argtypes = [vp]
+    lib.gsm_set_static.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, dbl, dbl, vp]
+    lib.gsm_set_blocks.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), vp, C.POINTER(i64), vp]
+    lib.gsm_set_centres.argtypes = [vp, vp, i32, vp]
+    lib.gsm_init_loss.argtypes = [vp, vp, vp, vp, vp]
+    lib.gsm_residual.argtypes = [vp, vp, vp, vp]
+    lib.gsm_run_replay.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]
+    lib.gsm_propose_philox.argtypes = [vp, i32, i64, vp, C.POINTER(RfParams), vp, vp, vp, vp, i64, vp, vp]
+    lib.gsm_run_philox.argtypes = [vp, i32, i64, i32, vp, C.POINTER(RfParams), vp, vp, vp, vp, vp, vp, vp]
+    lib.gsm_enable_timing.argtypes = [vp, i32]
+    lib.gsm_last_timing.argtypes = [vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(dbl), C.POINTER(i32)]
+    lib.gsm_philox_selftest.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    for name in declared_symbols():
+        fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+        if name not in ("gsm_version", "gsm_last_error"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def philox4x32_10(ctr, key):
+    """One Philox block through the library (host path; the device uses the same inline function)."""
+    lib = load()
+    c = (C.c_uint32 * 4)(*[int(v) & 0xFFFFFFFF for v in ctr])
+    k = (C.c_uint32 * 2)(*[int(v) & 0xFFFFFFFF for v in key])
+    o = (C.c_uint32 * 4)()
+    lib.gsm_philox_selftest(c, k, o)
+    return [int(v) for v in o]

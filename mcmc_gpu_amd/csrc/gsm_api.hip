@@ -1,0 +1,423 @@
+// C ABI of libgsm_hip.so (see include/gsm.h for the contract and the reference interfaces replaced).
+#include "gsm_internal.h"
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+
+using namespace gsm;
+
+struct gsm_context {
+  int H = 0, W = 0, n_chains = 0, device = 0;
+  std::string err;
+  bool have_static = false, have_blocks = false, have_centres = false;
+  // owned device copies
+  double* d_static[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // surf velx vely dhdt smb weight
+  uint8_t* d_upd = nullptr;
+  uint8_t* d_mc = nullptr;
+  StaticFields S{};
+  int32_t *d_bh = nullptr, *d_bw = nullptr;
+  int64_t* d_mask_off = nullptr;
+  double* d_masks = nullptr;
+  double* d_twiddle = nullptr;
+  int32_t* d_tw_off = nullptr;
+  BlockTable B{};
+  int tile_cap = 0;
+  int32_t* d_centres = nullptr;
+  int n_centres = 0;
+  int32_t* d_err = nullptr;
+  // philox-mode scratch (two buffers)
+  struct Scratch {
+    int32_t* size_idx = nullptr;
+    int32_t* centre = nullptr;
+    double* u = nullptr;
+    double* fields = nullptr;
+    size_t recs = 0;
+  } scr[2];
+  int64_t field_stride = 0;
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_prop[2] = {nullptr, nullptr}, ev_step[2] = {nullptr, nullptr};
+  // timing
+  bool timing = false;
+  double t_step_ms = 0, t_prop_ms = 0;
+  int n_step_launch = 0, n_prop_launch = 0;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(gsm_handle h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_err = msg;
+  return code;
+}
+#define HIPCHK(h, expr)                                                                       \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return fail(h, GSM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+  } while (0)
+
+extern "C" const char* gsm_version(void) { return "gsm-hip 0.1 gfx950"; }
+
+extern "C" const char* gsm_last_error(gsm_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int gsm_create(gsm_handle* out, int32_t H, int32_t W, int32_t n_chains, int32_t dtype, int32_t device) {
+  if (!out) return fail(nullptr, GSM_E_ARG, "gsm_create: out is NULL");
+  *out = nullptr;
+  if (H < 3 || W < 3 || n_chains < 1) return fail(nullptr, GSM_E_ARG, "gsm_create: need H,W >= 3 and n_chains >= 1");
+  if ((int64_t)H * W > (1LL << 30)) return fail(nullptr, GSM_E_ARG, "gsm_create: grid too large");
+  if (dtype != 0) return fail(nullptr, GSM_E_UNSUPPORTED, "gsm_create: only dtype 0 (fp64 state) is built");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1)
+    return fail(nullptr, GSM_E_HIP, std::string("gsm_create: no HIP device: ") + hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail(nullptr, GSM_E_ARG, "gsm_create: device index out of range");
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, GSM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  gsm_context* c = new gsm_context();
+  c->H = H; c->W = W; c->n_chains = n_chains; c->device = device;
+  e = hipMalloc(&c->d_err, sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemset(c->d_err, 0, sizeof(int32_t));
+  if (e != hipSuccess) { delete c; return fail(nullptr, GSM_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+  *out = c;
+  return GSM_OK;
+}
+
+static void free_scratch(gsm_context* c) {
+  for (auto& s : c->scr) {
+    if (s.size_idx) hipFree(s.size_idx);
+    if (s.centre) hipFree(s.centre);
+    if (s.u) hipFree(s.u);
+    if (s.fields) hipFree(s.fields);
+    s = gsm_context::Scratch();
+  }
+}
+
+extern "C" int gsm_destroy(gsm_handle h) {
+  if (!h) return GSM_OK;
+  hipSetDevice(h->device);
+  for (auto& p : h->d_static) if (p) hipFree(p);
+  if (h->d_upd) hipFree(h->d_upd);
+  if (h->d_mc) hipFree(h->d_mc);
+  if (h->d_bh) hipFree(h->d_bh);
+  if (h->d_bw) hipFree(h->d_bw);
+  if (h->d_mask_off) hipFree(h->d_mask_off);
+  if (h->d_masks) hipFree(h->d_masks);
+  if (h->d_twiddle) hipFree(h->d_twiddle);
+  if (h->d_tw_off) hipFree(h->d_tw_off);
+  if (h->d_centres) hipFree(h->d_centres);
+  if (h->d_err) hipFree(h->d_err);
+  free_scratch(h);
+  for (int i = 0; i < 2; ++i) {
+    if (h->ev_prop[i]) hipEventDestroy(h->ev_prop[i]);
+    if (h->ev_step[i]) hipEventDestroy(h->ev_step[i]);
+  }
+  if (h->aux) hipStreamDestroy(h->aux);
+  delete h;
+  return GSM_OK;
+}
+
+template <class T>
+static hipError_t dup_device(T** dst, const T* src, size_t n, hipStream_t st) {
+  if (*dst) { hipFree(*dst); *dst = nullptr; }
+  hipError_t e = hipMalloc(dst, n * sizeof(T));
+  if (e != hipSuccess) return e;
+  return hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyDefault, st);
+}
+
+extern "C" int gsm_set_static(gsm_handle h, const double* surf, const double* velx, const double* vely,
+                              const double* dhdt, const double* smb, const double* crf_weight,
+                              const uint8_t* update_mask, const uint8_t* mc_mask, double resolution,
+                              double sigma_mc, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!surf || !velx || !vely || !dhdt || !smb || !update_mask || !mc_mask)
+    return fail(h, GSM_E_ARG, "gsm_set_static: NULL field");
+  if (!(resolution > 0.0) || !(sigma_mc > 0.0)) return fail(h, GSM_E_ARG, "gsm_set_static: resolution and sigma_mc must be > 0");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t n = (size_t)h->H * h->W;
+  const double* src[6] = {surf, velx, vely, dhdt, smb, crf_weight};
+  for (int i = 0; i < 6; ++i) {
+    if (!src[i]) { if (h->d_static[i]) { hipFree(h->d_static[i]); h->d_static[i] = nullptr; } continue; }
+    HIPCHK(h, dup_device(&h->d_static[i], src[i], n, st));
+  }
+  HIPCHK(h, dup_device(&h->d_upd, update_mask, n, st));
+  HIPCHK(h, dup_device(&h->d_mc, mc_mask, n, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  StaticFields& S = h->S;
+  S.surf = h->d_static[0]; S.velx = h->d_static[1]; S.vely = h->d_static[2];
+  S.dhdt = h->d_static[3]; S.smb = h->d_static[4]; S.weight = h->d_static[5];
+  S.upd = h->d_upd; S.mc = h->d_mc;
+  S.H = h->H; S.W = h->W;
+  S.res = resolution;
+  S.two_res = 2.0 * resolution;
+  S.two_sigma2 = 2 * (sigma_mc * sigma_mc);
+  h->have_static = true;
+  return GSM_OK;
+}
+
+extern "C" int gsm_set_blocks(gsm_handle h, int32_t n_sizes, const int32_t* bh, const int32_t* bw,
+                              const double* edge_masks_packed, const int64_t* mask_offsets, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (n_sizes < 1 || !bh || !bw) return fail(h, GSM_E_ARG, "gsm_set_blocks: empty block table");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  int max_bh = 0, max_bw = 0, cap = 0;
+  int64_t mask_total = 0;
+  for (int i = 0; i < n_sizes; ++i) {
+    if (bh[i] < 2 || bw[i] < 2 || (bh[i] & 1) || (bw[i] & 1))
+      return fail(h, GSM_E_ARG, "gsm_set_blocks: block sizes must be even and >= 2 (RandField.get_block_sizes makes them even)");
+    if (bh[i] > h->H || bw[i] > h->W)
+      return fail(h, GSM_E_ARG, "gsm_set_blocks: block larger than the grid (the reference's slices mismatch there)");
+    max_bh = std::max(max_bh, bh[i]);
+    max_bw = std::max(max_bw, bw[i]);
+    cap = std::max(cap, (bh[i] + 2) * (bw[i] + 2));
+    if (mask_offsets) mask_total = std::max<int64_t>(mask_total, mask_offsets[i] + (int64_t)bh[i] * bw[i]);
+  }
+  if (step_lds_bytes(cap) > 160 * 1024)
+    return fail(h, GSM_E_UNSUPPORTED, "gsm_set_blocks: (bh+2)*(bw+2) window does not fit the 160 KiB LDS tile");
+  HIPCHK(h, dup_device(&h->d_bh, bh, (size_t)n_sizes, st));
+  HIPCHK(h, dup_device(&h->d_bw, bw, (size_t)n_sizes, st));
+  if (edge_masks_packed && mask_offsets) {
+    HIPCHK(h, dup_device(&h->d_mask_off, mask_offsets, (size_t)n_sizes, st));
+    HIPCHK(h, dup_device(&h->d_masks, edge_masks_packed, (size_t)mask_total, st));
+  } else {
+    if (h->d_masks) { hipFree(h->d_masks); h->d_masks = nullptr; }
+    if (h->d_mask_off) { hipFree(h->d_mask_off); h->d_mask_off = nullptr; }
+  }
+  // twiddle tables: for each distinct length n, (cos, sin)(2 pi m / n), m = 0..n-1
+  const int max_len = std::max(max_bh, max_bw);
+  std::vector<int32_t> off(max_len + 1, -1);
+  std::vector<double> tw;
+  for (int i = 0; i < n_sizes; ++i)
+    for (int n : {bh[i], bw[i]})
+      if (off[n] < 0) {
+        off[n] = (int32_t)tw.size();
+        for (int m = 0; m < n; ++m) {
+          const double ang = 2.0 * M_PI * (double)m / (double)n;
+          tw.push_back(cos(ang));
+          tw.push_back(sin(ang));
+        }
+      }
+  HIPCHK(h, dup_device(&h->d_twiddle, tw.data(), tw.size(), st));
+  HIPCHK(h, dup_device(&h->d_tw_off, off.data(), off.size(), st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  h->B.bh = h->d_bh; h->B.bw = h->d_bw; h->B.masks = h->d_masks; h->B.mask_off = h->d_mask_off;
+  h->B.n_sizes = n_sizes; h->B.max_bh = max_bh; h->B.max_bw = max_bw;
+  h->tile_cap = cap;
+  h->field_stride = (int64_t)max_bh * max_bw;
+  h->have_blocks = true;
+  free_scratch(h);
+  return GSM_OK;
+}
+
+extern "C" int gsm_set_centres(gsm_handle h, const int32_t* cells, int32_t n_cells, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!cells || n_cells < 1) return fail(h, GSM_E_ARG, "gsm_set_centres: empty centre list");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, dup_device(&h->d_centres, cells, (size_t)n_cells, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  h->n_centres = n_cells;
+  h->have_centres = true;
+  return GSM_OK;
+}
+
+extern "C" int gsm_init_loss(gsm_handle h, const double* beds, double* loss_sum, double* loss0, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_init_loss: call gsm_set_static first");
+  if (!beds || !loss_sum) return fail(h, GSM_E_ARG, "gsm_init_loss: NULL pointer");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_init_loss(h->S, h->n_chains, beds, loss_sum, loss0, (hipStream_t)stream));
+  return GSM_OK;
+}
+
+extern "C" int gsm_residual(gsm_handle h, const double* beds, double* residual, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_residual: call gsm_set_static first");
+  if (!beds || !residual) return fail(h, GSM_E_ARG, "gsm_residual: NULL pointer");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_residual(h->S, h->n_chains, beds, residual, (hipStream_t)stream));
+  return GSM_OK;
+}
+
+static int check_device_flag(gsm_handle h, hipStream_t st, const char* who) {
+  int32_t flag = 0;
+  HIPCHK(h, hipMemcpyAsync(&flag, h->d_err, sizeof(flag), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (flag) {
+    hipMemsetAsync(h->d_err, 0, sizeof(int32_t), st);
+    hipStreamSynchronize(st);
+    return fail(h, GSM_E_DEVICE_DATA, std::string(who) + ": size index or block centre out of range in device data (those steps were skipped)");
+  }
+  return GSM_OK;
+}
+
+extern "C" int gsm_run_replay(gsm_handle h, int32_t n_steps, double* beds, uint32_t* resampled, double* loss_sum,
+                              const int32_t* size_idx, const int32_t* centre, const double* u,
+                              const double* fields, int64_t field_stride, double* loss, uint8_t* accept,
+                              void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!h->have_static || !h->have_blocks) return fail(h, GSM_E_STATE, "gsm_run_replay: call gsm_set_static and gsm_set_blocks first");
+  if (n_steps < 0) return fail(h, GSM_E_ARG, "gsm_run_replay: n_steps < 0");
+  if (n_steps == 0) return GSM_OK;
+  if (!beds || !resampled || !loss_sum || !size_idx || !centre || !u || !fields || !loss || !accept)
+    return fail(h, GSM_E_ARG, "gsm_run_replay: NULL pointer");
+  if (field_stride < (int64_t)h->B.max_bh * h->B.max_bw)
+    return fail(h, GSM_E_ARG, "gsm_run_replay: field_stride smaller than the largest block");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  StepArgs a{};
+  a.S = h->S; a.B = h->B;
+  a.n_chains = h->n_chains; a.n_steps = n_steps; a.tile_cap = h->tile_cap;
+  a.beds = beds; a.resampled = resampled; a.loss_sum = loss_sum;
+  a.size_idx = size_idx; a.centre = centre; a.u = u; a.fields = fields; a.field_stride = field_stride;
+  a.loss = loss; a.accept = accept; a.blocks = nullptr;
+  a.rec_stride = n_steps; a.rec_offset = 0; a.in_stride = n_steps;
+  a.err_flag = h->d_err;
+  HIPCHK(h, launch_step(a, st));
+  return check_device_flag(h, st, "gsm_run_replay");
+}
+
+static int check_propose_ready(gsm_handle h, const gsm_rf_params* rf, const char* who) {
+  if (!h->have_blocks || !h->d_masks) return fail(h, GSM_E_STATE, std::string(who) + ": call gsm_set_blocks with edge masks first");
+  if (!h->have_centres) return fail(h, GSM_E_STATE, std::string(who) + ": call gsm_set_centres first");
+  if (!rf) return fail(h, GSM_E_ARG, std::string(who) + ": rf is NULL");
+  if (rf->model < 0 || rf->model > 2) return fail(h, GSM_E_ARG, std::string(who) + ": unknown covariance model");
+  if (!(rf->resolution > 0.0)) return fail(h, GSM_E_ARG, std::string(who) + ": rf.resolution must be > 0");
+  if (rf->model == GSM_MODEL_MATERN && !(rf->smoothness > 0.0))
+    return fail(h, GSM_E_ARG, std::string(who) + ": Matern needs smoothness > 0");
+  const size_t lds = ((size_t)4 * h->B.max_bh * (h->B.max_bw / 2 + 1) + 2 * h->B.max_bh + 2 * h->B.max_bw + 8) * 8;
+  if (lds > 160 * 1024) return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": block too large for the proposal kernel's LDS");
+  return GSM_OK;
+}
+
+static ProposeArgs make_propose(gsm_handle h, const gsm_rf_params* rf, int n_steps, int64_t step0, const uint64_t* seeds) {
+  ProposeArgs p{};
+  p.B = h->B; p.rf = *rf; p.H = h->H; p.W = h->W;
+  p.n_chains = h->n_chains; p.n_steps = n_steps; p.step0 = step0; p.seeds = seeds;
+  p.centres = h->d_centres; p.n_centres = h->n_centres;
+  p.twiddle = h->d_twiddle; p.tw_off = h->d_tw_off;
+  return p;
+}
+
+extern "C" int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, const uint64_t* seeds,
+                                  const gsm_rf_params* rf, int32_t* size_idx, int32_t* centre, double* u,
+                                  double* fields, int64_t field_stride, double* rf_scalars, void* stream) {
+  if (!h) return GSM_E_ARG;
+  int rc = check_propose_ready(h, rf, "gsm_propose_philox");
+  if (rc) return rc;
+  if (n_steps < 1 || n_steps > 65535) return fail(h, GSM_E_ARG, "gsm_propose_philox: n_steps must be in [1, 65535]");
+  if (!seeds || !size_idx || !centre || !u || !fields) return fail(h, GSM_E_ARG, "gsm_propose_philox: NULL pointer");
+  if (field_stride < (int64_t)h->B.max_bh * h->B.max_bw) return fail(h, GSM_E_ARG, "gsm_propose_philox: field_stride too small");
+  HIPCHK(h, hipSetDevice(h->device));
+  ProposeArgs p = make_propose(h, rf, n_steps, step0, seeds);
+  p.size_idx = size_idx; p.centre = centre; p.u = u; p.fields = fields; p.field_stride = field_stride;
+  p.rf_scalars = rf_scalars;
+  HIPCHK(h, launch_propose(p, (hipStream_t)stream));
+  return GSM_OK;
+}
+
+extern "C" int gsm_enable_timing(gsm_handle h, int32_t on) {
+  if (!h) return GSM_E_ARG;
+  h->timing = on != 0;
+  return GSM_OK;
+}
+
+extern "C" int gsm_last_timing(gsm_handle h, double* step_ms, int32_t* step_launches, double* prop_ms, int32_t* prop_launches) {
+  if (!h) return GSM_E_ARG;
+  if (step_ms) *step_ms = h->n_step_launch ? h->t_step_ms / h->n_step_launch : 0.0;
+  if (step_launches) *step_launches = h->n_step_launch;
+  if (prop_ms) *prop_ms = h->n_prop_launch ? h->t_prop_ms / h->n_prop_launch : 0.0;
+  if (prop_launches) *prop_launches = h->n_prop_launch;
+  return GSM_OK;
+}
+
+extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int32_t batch, const uint64_t* seeds,
+                              const gsm_rf_params* rf, double* beds, uint32_t* resampled, double* loss_sum,
+                              double* loss, uint8_t* accept, int32_t* blocks, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_run_philox: call gsm_set_static first");
+  int rc = check_propose_ready(h, rf, "gsm_run_philox");
+  if (rc) return rc;
+  if (n_steps < 0) return fail(h, GSM_E_ARG, "gsm_run_philox: n_steps < 0");
+  if (n_steps == 0) return GSM_OK;
+  if (batch < 1 || batch > 65535) return fail(h, GSM_E_ARG, "gsm_run_philox: batch must be in [1, 65535]");
+  if (!seeds || !beds || !resampled || !loss_sum || !loss || !accept) return fail(h, GSM_E_ARG, "gsm_run_philox: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (batch > n_steps) batch = n_steps;
+  // scratch
+  const size_t recs = (size_t)h->n_chains * batch;
+  for (auto& s : h->scr) {
+    if (s.recs >= recs) continue;
+    if (s.size_idx) { hipFree(s.size_idx); hipFree(s.centre); hipFree(s.u); hipFree(s.fields); s = gsm_context::Scratch(); }
+    HIPCHK(h, hipMalloc(&s.size_idx, recs * sizeof(int32_t)));
+    HIPCHK(h, hipMalloc(&s.centre, recs * 2 * sizeof(int32_t)));
+    HIPCHK(h, hipMalloc(&s.u, recs * sizeof(double)));
+    HIPCHK(h, hipMalloc(&s.fields, recs * (size_t)h->field_stride * sizeof(double)));
+    s.recs = recs;
+  }
+  if (!h->aux) HIPCHK(h, hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    if (!h->ev_prop[i]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_prop[i], hipEventDisableTiming));
+    if (!h->ev_step[i]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_step[i], hipEventDisableTiming));
+  }
+  const int n_batches = (n_steps + batch - 1) / batch;
+  std::vector<hipEvent_t> tev;  // timing events: (prop start, prop stop, step start, step stop) per batch
+  if (h->timing) {
+    tev.resize((size_t)n_batches * 4);
+    for (auto& e : tev) HIPCHK(h, hipEventCreate(&e));
+  }
+  // order the aux stream behind everything already queued on the caller's stream (seeds upload etc.)
+  HIPCHK(h, hipEventRecord(h->ev_step[0], st));
+  HIPCHK(h, hipStreamWaitEvent(h->aux, h->ev_step[0], 0));
+
+  auto issue_propose = [&](int k) -> int {
+    const int nb = std::min(batch, n_steps - k * batch);
+    auto& s = h->scr[k & 1];
+    if (k >= 2) HIPCHK(h, hipStreamWaitEvent(h->aux, h->ev_step[k & 1], 0));  // buffer free again
+    ProposeArgs p = make_propose(h, rf, nb, step0 + (int64_t)k * batch, seeds);
+    p.size_idx = s.size_idx; p.centre = s.centre; p.u = s.u; p.fields = s.fields; p.field_stride = h->field_stride;
+    p.rf_scalars = nullptr;
+    if (h->timing) HIPCHK(h, hipEventRecord(tev[4 * k], h->aux));
+    HIPCHK(h, launch_propose(p, h->aux));
+    if (h->timing) HIPCHK(h, hipEventRecord(tev[4 * k + 1], h->aux));
+    HIPCHK(h, hipEventRecord(h->ev_prop[k & 1], h->aux));
+    return GSM_OK;
+  };
+
+  rc = issue_propose(0);
+  if (rc) return rc;
+  for (int k = 0; k < n_batches; ++k) {
+    if (k + 1 < n_batches) { rc = issue_propose(k + 1); if (rc) return rc; }
+    const int nb = std::min(batch, n_steps - k * batch);
+    auto& s = h->scr[k & 1];
+    HIPCHK(h, hipStreamWaitEvent(st, h->ev_prop[k & 1], 0));
+    StepArgs a{};
+    a.S = h->S; a.B = h->B;
+    a.n_chains = h->n_chains; a.n_steps = nb; a.tile_cap = h->tile_cap;
+    a.beds = beds; a.resampled = resampled; a.loss_sum = loss_sum;
+    a.size_idx = s.size_idx; a.centre = s.centre; a.u = s.u; a.fields = s.fields; a.field_stride = h->field_stride;
+    a.loss = loss; a.accept = accept; a.blocks = blocks;
+    a.rec_stride = n_steps; a.rec_offset = (int64_t)k * batch; a.in_stride = nb;
+    a.err_flag = h->d_err;
+    if (h->timing) HIPCHK(h, hipEventRecord(tev[4 * k + 2], st));
+    HIPCHK(h, launch_step(a, st));
+    if (h->timing) HIPCHK(h, hipEventRecord(tev[4 * k + 3], st));
+    HIPCHK(h, hipEventRecord(h->ev_step[k & 1], st));
+  }
+  rc = check_device_flag(h, st, "gsm_run_philox");
+  HIPCHK(h, hipStreamSynchronize(h->aux));
+  if (h->timing) {
+    h->t_step_ms = h->t_prop_ms = 0;
+    h->n_step_launch = h->n_prop_launch = 0;
+    for (int k = 0; k < n_batches; ++k) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, tev[4 * k], tev[4 * k + 1]) == hipSuccess) { h->t_prop_ms += ms; h->n_prop_launch++; }
+      if (hipEventElapsedTime(&ms, tev[4 * k + 2], tev[4 * k + 3]) == hipSuccess) { h->t_step_ms += ms; h->n_step_launch++; }
+    }
+    for (auto& e : tev) hipEventDestroy(e);
+  }
+  return rc;
+}

@@ -1,0 +1,322 @@
+// Metropolis step kernels for gfx950 (MI355X): one 256-thread workgroup per chain, the proposal
+// window (+1-cell halo) of the chain's bed staged in LDS, all steps of a launch looped inside the kernel.
+//
+// Replaces the loop body of chain_crf.run (reference gstatsMCMC/MCMC.py:1263-1360):
+//   window/clipping         MCMC.py:1266-1276
+//   perturb + update mask   MCMC.py:1279-1290
+//   residual on window+halo MCMC.py:1293-1315 -> Topography.get_mass_conservation_residual (Topography.py:592-600)
+//   Gaussian loss           MCMC.py:1318      -> chain.loss (MCMC.py:1021-1044)
+//   thickness guard         MCMC.py:1321-1329
+//   accept / bookkeeping    MCMC.py:1331-1360
+//
+// What is NOT done the reference's way, and why the result is the same:
+//   * No residual array is carried.  The edge taper is exactly 0 on the block border (MCMC.py:583-623 with
+//     the driver's logistic parameters), so a proposal changes the residual only inside its window and the
+//     carried array always equals a recompute from the current bed.  The kernel recomputes the window's OLD
+//     residuals from the staged bed, applies the perturbation in LDS and recomputes the NEW ones:
+//         sum_next = sum_prev - sum_window(old r^2) + sum_window(new r^2)
+//     with sum_prev kept as a compensated (hi, lo) pair, instead of the O(H*W) gather + nansum per step.
+//     Arithmetic per residual is the reference's, operation for operation (no FMA contraction: this file is
+//     built with -ffp-contract=off), so only the summation order differs (|rel diff| ~1e-15, test bound 1e-10).
+//   * Full-grid copies (MCMC.py:1284, :1288, :1308, :1338) do not exist; accepted windows are written back.
+//
+// HBM traffic per chain-step: read (bh+2)(bw+2) bed cells; on accept write bh*bw bed cells and
+// read-modify-write bh*bw uint32 resampled counts.  Static fields are shared by all chains (L2-resident).
+
+#include "gsm_internal.h"
+#include <math.h>
+
+namespace gsm {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+__device__ __forceinline__ uint32_t magic_for(uint32_t d) {
+  // q = __umulhi(n, M) == n / d for n*d < 2^32 (here n < 2^16, d < 2^8)
+  return (uint32_t)(0xFFFFFFFFu / d) + 1u;
+}
+
+// Residual of cell (r, c) of the full grid.  `bed_at(rr, cc)` returns the bed value of a grid cell.
+// np.gradient semantics: interior (f[i+1]-f[i-1])/(2.0*h); first/last (f[1]-f[0])/h, (f[-1]-f[-2])/h.
+template <class BedAt>
+__device__ __forceinline__ double cell_residual(const StaticFields& S, int r, int c, BedAt bed_at) {
+  const int W = S.W, H = S.H;
+  const int cl = (c == 0) ? 0 : c - 1;
+  const int cr = (c == W - 1) ? W - 1 : c + 1;
+  const int ru = (r == 0) ? 0 : r - 1;
+  const int rd = (r == H - 1) ? H - 1 : r + 1;
+  const double denx = (cr - cl == 2) ? S.two_res : S.res;
+  const double deny = (rd - ru == 2) ? S.two_res : S.res;
+  const int gl = r * W + cl, gr = r * W + cr, gu = ru * W + c, gd = rd * W + c, g = r * W + c;
+  const double qxr = S.velx[gr] * (S.surf[gr] - bed_at(r, cr));
+  const double qxl = S.velx[gl] * (S.surf[gl] - bed_at(r, cl));
+  const double qyd = S.vely[gd] * (S.surf[gd] - bed_at(rd, c));
+  const double qyu = S.vely[gu] * (S.surf[gu] - bed_at(ru, c));
+  const double dx = (qxr - qxl) / denx;
+  const double dy = (qyd - qyu) / deny;
+  return ((dx + dy) + S.dhdt[g]) - S.smb[g];
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+
+__device__ __forceinline__ void two_sum(double a, double b, double& s, double& e) {
+  s = a + b;
+  const double bb = s - a;
+  e = (a - (s - bb)) + (b - bb);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// step kernel
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
+  extern __shared__ double lds[];
+  double* tile = lds;
+  double* red = lds + a.tile_cap;  // [kWaves][3]
+
+  const StaticFields& S = a.S;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int chain = blockIdx.x;
+  const int H = S.H, W = S.W;
+  const size_t plane = (size_t)H * W;
+  double* bed = a.beds + (size_t)chain * plane;
+  uint32_t* resamp = a.resampled + (size_t)chain * plane;
+
+  double s_hi = a.loss_sum[2 * chain], s_lo = a.loss_sum[2 * chain + 1];
+  double loss_prev = (s_hi + s_lo) / S.two_sigma2;
+
+  for (int s = 0; s < a.n_steps; ++s) {
+    const int64_t rin = (int64_t)chain * a.in_stride + s;
+    const int64_t rout = (int64_t)chain * a.rec_stride + a.rec_offset + s;
+    const int si = a.size_idx[rin];
+    const int row = a.centre[2 * rin], col = a.centre[2 * rin + 1];
+    if (si < 0 || si >= a.B.n_sizes || row < 0 || row >= H || col < 0 || col >= W) {
+      if (tid == 0) {
+        atomicExch(a.err_flag, 1);
+        a.loss[rout] = loss_prev;
+        a.accept[rout] = 0;
+        if (a.blocks) { a.blocks[4 * rout] = row; a.blocks[4 * rout + 1] = col; a.blocks[4 * rout + 2] = 0; a.blocks[4 * rout + 3] = 0; }
+      }
+      continue;  // uniform across the workgroup
+    }
+    const int bh = a.B.bh[si], bw = a.B.bw[si];
+    const double uu = a.u[rin];
+    const double* fld = a.fields + rin * a.field_stride;
+
+    // window, clipped to the grid, and the matching sub-block of f (MCMC.py:1266-1276)
+    const int r0 = max(0, row - bh / 2), r1 = min(H, row + bh / 2);
+    const int c0 = max(0, col - bw / 2), c1 = min(W, col + bw / 2);
+    const int mr0 = max(bh - r1, 0), mc0 = max(bw - c1, 0);
+    const int wh = r1 - r0, ww = c1 - c0;
+    // halo window (MCMC.py:1293-1297)
+    const int hr0 = max(0, r0 - 1), hr1 = min(H, r1 + 1);
+    const int hc0 = max(0, c0 - 1), hc1 = min(W, c1 + 1);
+    const int th = hr1 - hr0, tw = hc1 - hc0;
+    const int ncell = th * tw, nwin = wh * ww;
+    const uint32_t m_tw = magic_for((uint32_t)tw), m_ww = magic_for((uint32_t)max(ww, 1));
+
+    // A: stage the bed window + halo
+    for (int i = tid; i < ncell; i += kBlock) {
+      const int lr = (int)__umulhi((uint32_t)i, m_tw);
+      const int lc = i - lr * tw;
+      tile[i] = bed[(size_t)(hr0 + lr) * W + hc0 + lc];
+    }
+    __syncthreads();
+
+    auto tile_at = [&](int rr, int cc) { return tile[(rr - hr0) * tw + (cc - hc0)]; };
+
+    // B: sum of squared residuals of the window under the current bed
+    double acc_old = 0.0;
+    for (int i = tid; i < nwin; i += kBlock) {
+      const int wr = (int)__umulhi((uint32_t)i, m_ww);
+      const int wc = i - wr * ww;
+      const int r = r0 + wr, c = c0 + wc;
+      if (S.mc[r * W + c] == 1) {
+        const double v = cell_residual(S, r, c, tile_at);
+        if (!isnan(v)) acc_old += v * v;
+      }
+    }
+    __syncthreads();
+
+    // C: candidate bed in place (perturbation, update mask) and thickness guard
+    int guard = 0;
+    for (int i = tid; i < nwin; i += kBlock) {
+      const int wr = (int)__umulhi((uint32_t)i, m_ww);
+      const int wc = i - wr * ww;
+      const int r = r0 + wr, c = c0 + wc;
+      const int g = r * W + c;
+      if (S.upd[g]) {
+        const double f = fld[(mr0 + wr) * bw + mc0 + wc];
+        const double pert = S.weight ? f * S.weight[g] : f;
+        const int t = (r - hr0) * tw + (c - hc0);
+        const double bn = tile[t] + pert;
+        tile[t] = bn;
+        if (S.surf[g] - bn <= 0.0) guard = 1;
+      }
+    }
+    __syncthreads();
+
+    // D: sum of squared residuals of the window under the candidate bed
+    double acc_new = 0.0;
+    for (int i = tid; i < nwin; i += kBlock) {
+      const int wr = (int)__umulhi((uint32_t)i, m_ww);
+      const int wc = i - wr * ww;
+      const int r = r0 + wr, c = c0 + wc;
+      if (S.mc[r * W + c] == 1) {
+        const double v = cell_residual(S, r, c, tile_at);
+        if (!isnan(v)) acc_new += v * v;
+      }
+    }
+    acc_old = wave_sum(acc_old);
+    acc_new = wave_sum(acc_new);
+    const int any_guard = __any(guard);
+    if (lane == 0) {
+      red[wave * 3 + 0] = acc_old;
+      red[wave * 3 + 1] = acc_new;
+      red[wave * 3 + 2] = any_guard ? 1.0 : 0.0;
+    }
+    __syncthreads();
+
+    // every thread evaluates the same decision from the same partials (fixed order => deterministic)
+    double so = 0.0, sn = 0.0, gd = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) { so += red[w * 3]; sn += red[w * 3 + 1]; gd += red[w * 3 + 2]; }
+    double c_hi, c_err;
+    two_sum(s_hi, sn - so, c_hi, c_err);
+    const double c_lo = s_lo + c_err;
+    double loss_next = (c_hi + c_lo) / S.two_sigma2;
+    if (gd > 0.0) loss_next = INFINITY;
+    const double p_acc = (loss_prev > loss_next) ? 1.0 : fmin(1.0, exp(loss_prev - loss_next));
+    const bool acc = (uu <= p_acc);
+
+    // E: commit
+    if (acc) {
+      for (int i = tid; i < nwin; i += kBlock) {
+        const int wr = (int)__umulhi((uint32_t)i, m_ww);
+        const int wc = i - wr * ww;
+        const int r = r0 + wr, c = c0 + wc;
+        const size_t g = (size_t)r * W + c;
+        if (S.upd[g]) {
+          bed[g] = tile[(r - hr0) * tw + (c - hc0)];
+          if (S.upd[g] == 1) resamp[g] += 1u;
+        }
+      }
+      // renormalise the pair
+      two_sum(c_hi, c_lo, s_hi, s_lo);
+      loss_prev = loss_next;
+    }
+    if (tid == 0) {
+      a.loss[rout] = loss_prev;
+      a.accept[rout] = acc ? 1 : 0;
+      if (a.blocks) { a.blocks[4 * rout] = row; a.blocks[4 * rout + 1] = col; a.blocks[4 * rout + 2] = bh; a.blocks[4 * rout + 3] = bw; }
+    }
+    __syncthreads();  // tile/red reuse + this step's bed stores visible to the next step's loads
+  }
+  if (tid == 0) {
+    a.loss_sum[2 * chain] = s_hi;
+    a.loss_sum[2 * chain + 1] = s_lo;
+  }
+}
+
+size_t step_lds_bytes(int tile_cap) { return ((size_t)tile_cap + 3 * kWaves) * sizeof(double); }
+
+hipError_t launch_step(const StepArgs& a, hipStream_t st) {
+  const size_t lds = step_lds_bytes(a.tile_cap);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(step_kernel, dim3(a.n_chains), dim3(kBlock), lds, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// full-grid residual + loss of the current beds (MCMC.py:1189-1195)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void init_loss_kernel(const StaticFields S, const double* beds,
+                                                           double* loss_sum, double* loss0) {
+  __shared__ double red[kWaves * 2];
+  const int chain = blockIdx.x, tid = threadIdx.x;
+  const size_t plane = (size_t)S.H * S.W;
+  const double* bed = beds + (size_t)chain * plane;
+  auto bed_at = [&](int rr, int cc) { return bed[(size_t)rr * S.W + cc]; };
+  // per-thread compensated partial
+  double hi = 0.0, lo = 0.0;
+  for (int g = tid; g < (int)plane; g += kBlock) {
+    if (S.mc[g] == 1) {
+      const int r = g / S.W, c = g - r * S.W;
+      const double v = cell_residual(S, r, c, bed_at);
+      if (!isnan(v)) {
+        double s, e;
+        two_sum(hi, v * v, s, e);
+        hi = s;
+        lo += e;
+      }
+    }
+  }
+  // wave tree on (hi, lo) with two_sum at each level
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ohi = __shfl_down(hi, off, 64), olo = __shfl_down(lo, off, 64);
+    double s, e;
+    two_sum(hi, ohi, s, e);
+    hi = s;
+    lo += olo + e;
+  }
+  if ((tid & 63) == 0) { red[(tid >> 6) * 2] = hi; red[(tid >> 6) * 2 + 1] = lo; }
+  __syncthreads();
+  if (tid == 0) {
+    double th = 0.0, tl = 0.0;
+    for (int w = 0; w < kWaves; ++w) {
+      double s, e;
+      two_sum(th, red[2 * w], s, e);
+      th = s;
+      tl += red[2 * w + 1] + e;
+    }
+    double nh, nl;
+    two_sum(th, tl, nh, nl);
+    loss_sum[2 * chain] = nh;
+    loss_sum[2 * chain + 1] = nl;
+    if (loss0) loss0[chain] = (nh + nl) / S.two_sigma2;
+  }
+}
+
+hipError_t launch_init_loss(const StaticFields& S, int n_chains, const double* beds, double* loss_sum,
+                            double* loss0, hipStream_t st) {
+  hipLaunchKernelGGL(init_loss_kernel, dim3(n_chains), dim3(kBlock), 0, st, S, beds, loss_sum, loss0);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Topography.get_mass_conservation_residual for a batch of beds (Topography.py:592-600)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void residual_kernel(const StaticFields S, int n_chains, const double* beds,
+                                                          double* out) {
+  const size_t plane = (size_t)S.H * S.W;
+  const size_t total = plane * (size_t)n_chains;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const size_t chain = i / plane;
+    const int g = (int)(i - chain * plane);
+    const int r = g / S.W, c = g - r * S.W;
+    const double* bed = beds + chain * plane;
+    auto bed_at = [&](int rr, int cc) { return bed[(size_t)rr * S.W + cc]; };
+    out[i] = cell_residual(S, r, c, bed_at);
+  }
+}
+
+hipError_t launch_residual(const StaticFields& S, int n_chains, const double* beds, double* out, hipStream_t st) {
+  const size_t total = (size_t)S.H * S.W * n_chains;
+  int grid = (int)((total + kBlock - 1) / kBlock);
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(residual_kernel, dim3(grid), dim3(kBlock), 0, st, S, n_chains, beds, out);
+  return hipGetLastError();
+}
+
+}  // namespace gsm

@@ -1,0 +1,76 @@
+"""-m gpu: the Philox proposal generator against its CPU restatement (oracle/philox_oracle.py)."""
+import numpy as np
+import pytest
+
+import mcmc_oracle as orc
+import philox_oracle as po
+from gpu_common import make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("model,iso,nug", [("Matern", True, 0.0), ("Gaussian", False, 4.0), ("Exponential", True, 0.0)])
+def test_proposals_match_oracle(model, iso, nug):
+    rfp = orc.RFParams(10e3, 50e3, 12e3, 40e3, 50, 150, nug, model, iso, 0.9125 if model == "Matern" else None)
+    eng, prob, cfg, pairs, masks, _ = make_engine(64, 3, rf_params=rfp)
+    seeds = [7, 2 ** 40 + 12345, 99]
+    rfp.resolution = prob["resolution"]
+    out = eng.propose_philox(5, 1000, seeds, rfp)
+    centres = np.flatnonzero(cfg.region_mask.ravel() == 1)
+    for c in range(3):
+        for s in range(5):
+            e = po.proposal(seeds[c], 1000 + s, rfp, pairs, masks, centres, 64, prob["resolution"])
+            assert int(out["size_idx"][c, s]) == e["size_idx"]
+            assert tuple(out["centre"][c, s].tolist()) == e["centre"]
+            assert float(out["u"][c, s]) == e["u"]
+            sc = out["rf_scalars"][c, s].cpu().numpy()
+            np.testing.assert_allclose(sc, [e["scale"], e["nug"], e["range_x"], e["range_y"]], rtol=1e-15)
+            bh, bw = e["field"].shape
+            f = out["fields"][c, s, : bh * bw].cpu().numpy().reshape(bh, bw)
+            np.testing.assert_allclose(f, e["field"], rtol=0, atol=po.field_atol(e))
+    eng.close()
+
+
+def test_proposals_256_blocks_match_oracle():
+    rfp = orc.standard_rf_params()
+    eng, prob, cfg, pairs, masks, _ = make_engine(256, 2)
+    rfp.resolution = prob["resolution"]
+    seeds = [11, 12]
+    out = eng.propose_philox(6, 0, seeds, rfp)
+    centres = np.flatnonzero(cfg.region_mask.ravel() == 1)
+    for c in range(2):
+        for s in range(6):
+            e = po.proposal(seeds[c], s, rfp, pairs, masks, centres, 256, prob["resolution"])
+            assert int(out["size_idx"][c, s]) == e["size_idx"]
+            bh, bw = e["field"].shape
+            f = out["fields"][c, s, : bh * bw].cpu().numpy().reshape(bh, bw)
+            np.testing.assert_allclose(f, e["field"], rtol=0, atol=po.field_atol(e))
+    eng.close()
+
+
+def test_run_philox_equals_propose_then_replay():
+    """gsm_run_philox (batched, two streams) == gsm_propose_philox + gsm_run_replay on the same counters,
+    and is independent of the batch size."""
+    rfp = orc.standard_rf_params()
+    eng, prob, cfg, pairs, masks, _ = make_engine(64, 4)
+    rfp.resolution = prob["resolution"]
+    seeds = [21, 22, 23, 24]
+    beds0 = np.stack([orc.chain_initial_bed(prob, c) for c in range(4)])
+    n = 37
+    eng.set_state(beds0)
+    lossA, accA, blkA = eng.run_philox(n, 5, seeds, rfp, batch=8)
+    bedA = eng.beds.cpu().numpy().copy()
+    resA = eng.resampled.cpu().numpy().copy()
+    eng.set_state(beds0)
+    lossB, accB, blkB = eng.run_philox(n, 5, seeds, rfp, batch=37)
+    assert np.array_equal(accA, accB) and np.array_equal(lossA, lossB) and np.array_equal(blkA, blkB)
+    assert np.array_equal(bedA, eng.beds.cpu().numpy())
+    eng.set_state(beds0)
+    p = eng.propose_philox(n, 5, seeds, rfp)
+    lossC, accC = eng.run_replay(p["size_idx"].cpu().numpy(), p["centre"].cpu().numpy(), p["u"].cpu().numpy(), p["fields"])
+    assert np.array_equal(accA, accC) and np.array_equal(lossA, lossC)
+    assert np.array_equal(bedA, eng.beds.cpu().numpy())
+    assert np.array_equal(resA, eng.resampled.cpu().numpy())
+    assert np.array_equal(blkA[..., 0], p["centre"].cpu().numpy()[..., 0])
+    assert 0.3 < accA.mean() <= 1.0
+    eng.close()
