@@ -1,0 +1,443 @@
+"""Host-side mirror of the reference's large-scale-chain interface (gstatsMCMC/MCMC_gpu.py namespace).
+
+Same class / function names, argument meaning, return tuples and exceptions as the reference, so that
+`from mcmc_gpu_amd import MCMC_gpu` can stand where `from gstatsMCMC import MCMC_gpu` stands in
+largeScaleChain_multiprocessing_GPU.py:
+
+    RandField                      gstatsMCMC/MCMC.py:433-778
+    chain_crf_gpu                  gstatsMCMC/MCMC_gpu.py:149-582 (and chain / chain_crf, MCMC.py:780-1443)
+    init_lsc_chain_by_instance     gstatsMCMC/MCMC.py:359-377   (returns the GPU class: fixes SURVEY section 9-1)
+    initiate_RF_by_instance        gstatsMCMC/MCMC.py:381-398
+
+The Metropolis loop itself never runs here: `run` hands whole segments of steps to libgsm_hip.so.
+Two draw modes:
+  'replay'  (default) -- the draws come from the two NumPy Generators exactly as in the reference (RandField.rng
+            for the proposal, chain.rng for centre and accept uniform, MCMC.py:742-778, :1253-1261, :1336), are
+            uploaded in chunks, and the device performs the steps.  Results equal the CPU chain_crf.run on the
+            same seeds (accept masks bit-exact, loss <= 1e-10 rel).  This mirrors the reference's own GPU class,
+            which also draws on the host (MCMC_gpu.py:368-369, :468).
+  'philox'  -- everything on the device with the counter-based generator (throughput mode, many chains).
+"""
+from __future__ import annotations
+
+import math
+import sys
+import time
+from copy import deepcopy
+
+import numpy as np
+
+from . import Topography  # noqa: F401  (re-exported like the reference namespace does)
+
+__all__ = ["RandField", "chain_crf_gpu", "init_lsc_chain_by_instance", "initiate_RF_by_instance",
+           "spectral_synthesis_field", "run_many", "min_dist_from_mask"]
+
+
+def min_dist_from_mask(xx, yy, mask):
+    """Distance from every cell to the nearest True cell of `mask` (Utilities.py:21-24)."""
+    from scipy.spatial import cKDTree
+    pts = np.array([xx[mask], yy[mask]]).T
+    if pts.shape[0] == 0:
+        raise ValueError("mask selects no cell")
+    return cKDTree(pts).query(np.array([xx.ravel(), yy.ravel()]).T)[0].reshape(xx.shape)
+
+
+def spectral_synthesis_field(RF, shape, res=1.0):
+    """FFT spectral-synthesis realisation with the reference's draw order (MCMC.py:176-254): scale, nugget,
+    range(s), two planes of normals, nugget normals.  Host generator of 'replay' mode."""
+    ny, nx = shape
+    rng = RF.rng
+    scale = rng.uniform(RF.scale_min, RF.scale_max) / 3.0
+    nug = rng.uniform(0.0, RF.nugget_max)
+    if RF.isotropic:
+        rx = ry = rng.uniform(RF.range_min_x, RF.range_max_x)
+    else:
+        rx = rng.uniform(RF.range_min_x, RF.range_max_x)
+        ry = rng.uniform(RF.range_min_y, RF.range_max_y)
+    div = {"Gaussian": np.sqrt(3), "Exponential": 3.0}.get(RF.model_name, 2.0)
+    a = np.sqrt((rx / div) * (ry / div))
+    kyv, kxv = np.meshgrid(np.fft.fftfreq(ny, d=res) * 2 * np.pi, np.fft.fftfreq(nx, d=res) * 2 * np.pi, indexing="ij")
+    k = np.sqrt(kxv ** 2 + kyv ** 2) + 1e-10
+    if RF.model_name == "Gaussian":
+        S = np.exp(-0.5 * (a * k) ** 2)
+    elif RF.model_name == "Exponential":
+        S = 1.0 / (1.0 + (a * k) ** 2) ** 1.5
+    else:
+        nu = RF.smoothness or 1.0
+        S = ((4 * np.pi * math.gamma(nu + 1) * (2 * nu) ** nu) / (math.gamma(nu) * a ** (2 * nu))) * \
+            ((2 * nu / (a ** 2) + 4 * np.pi * k ** 2) ** (-nu - 1))
+    white = rng.normal(size=(ny, nx)) + 1j * rng.normal(size=(ny, nx))
+    fld = np.fft.ifft2(white * np.sqrt(S)).real
+    fld = (fld - np.mean(fld)) / (np.std(fld) + 1e-12)
+    return fld * scale + rng.normal(0, np.sqrt(nug), size=(ny, nx))
+
+
+class RandField:
+    """Proposal description: covariance-model ranges, block-size table, edge taper (MCMC.py:433-778)."""
+
+    def __init__(self, range_min_x, range_max_x, range_min_y, range_max_y, scale_min, scale_max, nugget_max,
+                 model_name, isotropic, smoothness=None, rng_seed=None):
+        if rng_seed is None:
+            rng = np.random.default_rng()
+        elif isinstance(rng_seed, (int, np.integer)):
+            rng = np.random.default_rng(seed=int(rng_seed))
+        elif isinstance(rng_seed, np.random.Generator):
+            rng = rng_seed
+        else:
+            raise ValueError('Seed should be an integer, a NumPy random Generator, or None')
+        self.rng = rng
+        if (range_max_x < range_min_x) or (range_max_y < range_min_y):
+            print('the maximum range must be greater to equal to the minimum range')
+        self.range_max_x, self.range_max_y = range_max_x, range_max_y
+        self.range_min_x, self.range_min_y = range_min_x, range_min_y
+        self.scale_min, self.scale_max = scale_min, scale_max
+        self.nugget_max = nugget_max
+        if model_name not in ('Gaussian', 'Exponential', 'Matern'):
+            raise Exception('please put in a valid model_name, including Gaussian, Exponential, and Matern')
+        if model_name == 'Matern' and smoothness is None:
+            raise Exception('a smoothness value must be defined if model name is Matern')
+        self.smoothness = smoothness
+        self.model_name = model_name
+        self.isotropic = isotropic
+
+    def set_generation_method(self, spectral):
+        self.spectral = spectral
+
+    def set_block_sizes(self, min_block_x, max_block_x, min_block_y, max_block_y, steps=5):
+        self.min_block_x, self.min_block_y = min_block_x, min_block_y
+        self.max_block_x, self.max_block_y = max_block_x, max_block_y
+        self.steps = steps
+        self.pairs = self.get_block_sizes()
+
+    def set_weight_param(self, logis_func_L, logis_func_x0, logis_func_k, logis_func_offset, max_dist, resolution):
+        if not hasattr(self, 'pairs'):
+            raise Exception('It seems like the set_block_sizes has not been called yet before calling set_weight_param')
+        self.logistic_param = [logis_func_L, logis_func_x0, logis_func_k, logis_func_offset]
+        self.max_dist = max_dist
+        self.resolution = resolution
+        self.edge_masks = self.get_edge_masks()
+
+    def get_block_sizes(self):
+        width = np.linspace(self.min_block_x, self.max_block_x, self.steps, dtype=int)
+        height = np.linspace(self.min_block_y, self.max_block_y, self.steps, dtype=int)
+        w, h = np.meshgrid(width, height)
+        return np.array([(w // 2 * 2).flatten(), (h // 2 * 2).flatten()])
+
+    def _logistic(self, dist):
+        L, x0, k, off = self.logistic_param
+        resc = np.where(dist > self.max_dist, 1, dist / self.max_dist)
+        return resc, L / (1 + np.exp(-k * (resc - x0))) - off
+
+    def get_edge_masks(self):
+        if not hasattr(self, 'pairs'):
+            raise Exception('It seems like the set_block_sizes has not been called yet before calling get_edge_mask')
+        out = []
+        for n in range(self.pairs.shape[1]):
+            bw, bh = int(self.pairs[0, n]), int(self.pairs[1, n])
+            jj, ii = np.meshgrid(np.arange(bw), np.arange(bh))
+            # distance to the nearest border cell: the nearest one is straight up/down/left/right
+            dist = np.minimum(np.minimum(ii, bh - 1 - ii), np.minimum(jj, bw - 1 - jj)) * self.resolution
+            out.append(self._logistic(np.sqrt(dist ** 2))[1])
+        return out
+
+    def get_crf_weight(self, xx, yy, cond_data_mask):
+        dist = min_dist_from_mask(xx, yy, cond_data_mask == 1)
+        return self.get_crf_weight_from_dist(xx, yy, dist)
+
+    def get_crf_weight_from_dist(self, xx, yy, dist):
+        resc, logi = self._logistic(dist)
+        return logi - np.min(logi), dist, resc, logi
+
+    def get_random_field(self, X, Y, n=1):
+        raise NotImplementedError("the gstools randomisation-method generator (MCMC.py:625-687) is not available "
+                                  "in this build; use set_generation_method(True) (spectral synthesis)")
+
+    def get_rfblock(self):
+        """One masked proposal block with the reference's draw order (MCMC.py:742-778)."""
+        idx = self.rng.integers(low=0, high=self.pairs.shape[1], size=1)[0]
+        bw, bh = int(self.pairs[0, idx]), int(self.pairs[1, idx])
+        if not getattr(self, 'spectral', False):
+            return self.get_random_field(None, None)
+        while True:
+            f = spectral_synthesis_field(self, (bh, bw), res=self.resolution)
+            if np.sum(np.isnan(f)) == 0:
+                break
+            print('f have nan')
+        self._last_size_idx = int(idx)
+        return f * self.edge_masks[idx]
+
+
+class chain_crf_gpu:
+    """Large-scale random-field Metropolis chain executed on the MI355X (reference: chain / chain_crf /
+    chain_crf_gpu, MCMC.py:780-1443, MCMC_gpu.py:149-582).  All state lives in plain attributes so the
+    object can be rebuilt from a deep copy of its __dict__ (largeScaleChain_multiprocessing_GPU.py:56-75)."""
+
+    def __init__(self, xx, yy, initial_bed, surf, velx, vely, dhdt, smb, cond_bed, data_mask, grounded_ice_mask, resolution):
+        self.xx, self.yy = xx, yy
+        self.initial_bed = initial_bed
+        self.surf, self.velx, self.vely, self.dhdt, self.smb = surf, velx, vely, dhdt, smb
+        self.cond_bed = cond_bed
+        self.data_mask = data_mask
+        self.grounded_ice_mask = grounded_ice_mask
+        self.resolution = resolution
+        self.loss_function_list = []
+        self.sample_loc = None
+        shp = initial_bed.shape
+        if any(a.shape != shp for a in (surf, velx, vely, dhdt, smb, cond_bed, data_mask)):
+            raise Exception('the shape of bed, surf, velx, vely, dhdt, smb, radar_bed, data_mask need to be same')
+        self.rng_mode = 'replay'
+        self.replay_chunk = 256
+        self.philox_step = 0
+        self.philox_batch = 8
+
+    # ---- setters (MCMC.py:849-872, :950-1018, :1046-1081, :1098-1134) ---------------------------
+    def set_update_region(self, update_in_region, region_mask=[]):
+        self.update_in_region = update_in_region
+        if update_in_region is False:
+            self.region_mask = np.full(self.xx.shape, 1)
+        else:
+            if np.shape(region_mask) != self.xx.shape:
+                raise ValueError('the region_mask input is invalid. It has to be a 2D numpy array with the shape of the map')
+            self.region_mask = region_mask
+
+    def set_loss_type(self, sigma_mc=-1, massConvInRegion=True):
+        self.mc_region_mask = self.region_mask if massConvInRegion else np.full(self.xx.shape, 1)
+        self.sigma_mc = sigma_mc
+
+    def loss(self, massConvResidual, dataDiff):
+        loss_mc = np.nansum(np.square(massConvResidual[self.mc_region_mask == 1])) / (2 * self.sigma_mc ** 2)
+        return loss_mc + 0, loss_mc, 0
+
+    def set_random_generator(self, rng_seed=None):
+        if rng_seed is None:
+            rng = np.random.default_rng()
+        elif isinstance(rng_seed, (int, np.integer)):
+            rng = np.random.default_rng(seed=int(rng_seed))
+            self.rng_seed = int(rng_seed)
+        elif isinstance(rng_seed, np.random.Generator):
+            rng = rng_seed
+        else:
+            raise ValueError('Seed should be an integer, a NumPy random Generator, or None')
+        self.rng = rng
+
+    def set_sample_points_locations(self, loc):
+        self.sample_loc = loc
+
+    def set_update_type(self, block_type):
+        if block_type not in ('CRF_weight', 'CRF_rbf', 'RF'):
+            raise ValueError('The block_type argument should be one of the following: CRF_weight, CRF_rbf, RF')
+        self.block_type = block_type
+
+    def set_crf_data_weight(self, RF):
+        self.crf_data_weight = RF.get_crf_weight(self.xx, self.yy, self.data_mask)[0]
+
+    def set_rng_mode(self, mode, philox_batch=None):
+        """'replay' (NumPy draws, reference-identical chain) or 'philox' (device draws)."""
+        if mode not in ('replay', 'philox'):
+            raise ValueError("mode must be 'replay' or 'philox'")
+        self.rng_mode = mode
+        if philox_batch:
+            self.philox_batch = int(philox_batch)
+
+    # ---- engine plumbing ---------------------------------------------------------------------------
+    def _make_engine(self, RF, n_chains, device=None):
+        from .engine import GsmEngine
+        H, W = self.xx.shape
+        eng = GsmEngine(H, W, n_chains, device)
+        upd = self.region_mask if self.update_in_region else self.grounded_ice_mask
+        weight = self.crf_data_weight if self.block_type == 'CRF_weight' else None
+        eng.set_static(self.surf, self.velx, self.vely, self.dhdt, self.smb, weight, upd, self.mc_region_mask,
+                       self.resolution, self.sigma_mc)
+        eng.set_blocks(RF.pairs, RF.edge_masks)
+        if self.update_in_region:
+            eng.set_centres(self.region_mask)
+        else:
+            eng.set_centres(np.ones(self.xx.shape, dtype=np.uint8))
+        return eng
+
+    def _philox_seed(self):
+        seed = getattr(self, 'rng_seed', None)
+        if seed is None:
+            seed = int(self.rng.bit_generator.seed_seq.entropy) if hasattr(self.rng.bit_generator, 'seed_seq') else 0
+        return int(seed) & 0xFFFFFFFFFFFFFFFF
+
+    def _draw_chunk(self, RF, n):
+        """n steps of host draws in the reference's per-generator order."""
+        H, W = self.xx.shape
+        size_idx = np.empty(n, dtype=np.int32)
+        centre = np.empty((n, 2), dtype=np.int32)
+        u = np.empty(n)
+        fields = []
+        rng = self.rng
+        for s in range(n):
+            f = RF.get_rfblock()
+            fields.append(f)
+            size_idx[s] = RF._last_size_idx
+            if self.update_in_region:
+                while True:
+                    ix = rng.integers(low=0, high=H, size=1)[0]
+                    iy = rng.integers(low=0, high=W, size=1)[0]
+                    if self.region_mask[ix, iy] == 1:
+                        break
+            else:
+                ix = rng.integers(low=0, high=H, size=1)[0]
+                iy = rng.integers(low=0, high=W, size=1)[0]
+            centre[s] = (ix, iy)
+            u[s] = rng.random()
+        return size_idx, centre, u, fields
+
+    def _sample_indices(self):
+        loc = np.asarray(self.sample_loc)
+        ij = np.zeros(loc.shape, dtype=np.int64)
+        for k in range(loc.shape[0]):
+            i, j = np.where((self.xx == loc[k, 0]) & (self.yy == loc[k, 1]))
+            ij[k] = [int(i[0]), int(j[0])]
+        return ij
+
+    # ---- the chain ----------------------------------------------------------------------------------
+    def run(self, n_iter, RF, only_save_last_bed=False, info_per_iter=1000, plot=True, progress_bar=True):
+        """n_iter-1 Metropolis proposals from self.initial_bed; returns the reference's tuple
+        (bed or bed_cache, loss_mc_cache, loss_data_cache, loss_cache, step_cache, resampled_times,
+        blocks_cache[, sample_values]) as NumPy arrays (MCMC.py:1137-1443)."""
+        if not isinstance(RF, RandField):
+            raise TypeError('The arugment "RF" has to be an object of the class RandField')
+        if not getattr(RF, 'spectral', False):
+            raise NotImplementedError('only the spectral-synthesis generator (set_generation_method(True)) is built')
+        if not hasattr(self, 'rng'):
+            self.set_random_generator(getattr(self, 'rng_seed', None))
+        H, W = self.xx.shape
+        n_iter = int(n_iter)
+        if n_iter < 1:
+            raise ValueError('n_iter must be >= 1')
+        loss_cache = np.zeros(n_iter)
+        step_cache = np.zeros(n_iter)
+        blocks_cache = np.full((n_iter, 4), np.nan)
+        keep_all = not only_save_last_bed
+        track = self.sample_loc is not None
+        if keep_all:
+            bed_cache = np.zeros((n_iter, H, W))
+        if track:
+            ij = self._sample_indices()
+            sample_values = np.zeros((ij.shape[0], n_iter))
+
+        eng = self._make_engine(RF, 1)
+        try:
+            bed0 = np.asarray(self.initial_bed, dtype=np.float64)
+            loss_cache[0] = eng.set_state(bed0[None])[0]
+            if keep_all:
+                bed_cache[0] = bed0
+            if track:
+                sample_values[:, 0] = bed0[ij[:, 0], ij[:, 1]]
+            per_step = keep_all or track
+            chunk = 1 if per_step else (self.replay_chunk if self.rng_mode == 'replay' else max(n_iter - 1, 1))
+            t0 = time.time()
+            done = 1
+            next_info = info_per_iter
+            while done < n_iter:
+                n = min(chunk, n_iter - done)
+                if self.rng_mode == 'replay':
+                    si, ce, u, fields = self._draw_chunk(RF, n)
+                    loss, acc = eng.run_replay(si[None], ce[None], u[None], eng.pack_fields([fields]))
+                    blocks_cache[done:done + n, 0:2] = ce
+                    blocks_cache[done:done + n, 2] = eng.bh[si]
+                    blocks_cache[done:done + n, 3] = eng.bw[si]
+                else:
+                    loss, acc, blk = eng.run_philox(n, self.philox_step, [self._philox_seed()], RF, batch=self.philox_batch)
+                    self.philox_step += n
+                    blocks_cache[done:done + n] = blk[0]
+                loss_cache[done:done + n] = loss[0]
+                step_cache[done:done + n] = acc[0]
+                if per_step:
+                    b = eng.beds[0].cpu().numpy()
+                    if keep_all:
+                        bed_cache[done] = b
+                    if track:
+                        sample_values[:, done] = b[ij[:, 0], ij[:, 1]]
+                done += n
+                if progress_bar is not None and (done >= next_info or done == n_iter):
+                    next_info = done + info_per_iter
+                    el = time.time() - t0
+                    print(f"Chain {getattr(self, 'chain_id', 0)} ({str(getattr(self, 'seed', 'Unknown'))[:6]}): "
+                          f"{100 * (done - 1) / max(n_iter - 1, 1):3.0f}% | it/s: {(done - 1) / max(el, 1e-9):8.1f} | "
+                          f"n: {n_iter} | loss: {loss_cache[done - 1]:.3e} | acc: {step_cache[:done].sum() / done:.4f}",
+                          file=sys.stdout, flush=True)
+            bed_c = eng.beds[0].cpu().numpy()
+            resampled = eng.resampled[0].cpu().numpy().astype(np.float64)
+        finally:
+            eng.close()
+        loss_mc_cache = loss_cache.copy()
+        loss_data_cache = np.zeros(n_iter)
+        out = (bed_cache if keep_all else bed_c, loss_mc_cache, loss_data_cache, loss_cache, step_cache, resampled, blocks_cache)
+        return out + (sample_values,) if track else out
+
+
+def run_many(chain, RF, initial_beds, seeds, n_iter, batch=8, device=None, step0=0, return_device=False):
+    """Batched entry the reference lacks: n independent Philox-mode chains of one template (same static fields,
+    same RandField) on one GPU.  Returns a list of per-chain 7-tuples shaped like chain.run(..., only_save_last_bed=True)
+    (what Pool.starmap returns in largeScaleChain_mp, largeScaleChain_multiprocessing_GPU.py:84-85)."""
+    if not isinstance(RF, RandField):
+        raise TypeError('The arugment "RF" has to be an object of the class RandField')
+    beds = np.asarray(initial_beds, dtype=np.float64)
+    n_chains = beds.shape[0]
+    if len(seeds) != n_chains:
+        raise ValueError('need one seed per chain')
+    eng = chain._make_engine(RF, n_chains, device)
+    try:
+        loss0 = eng.set_state(beds)
+        n_steps = int(n_iter) - 1
+        if n_steps > 0:
+            loss, acc, blk = eng.run_philox(n_steps, step0, [int(s) & 0xFFFFFFFFFFFFFFFF for s in seeds], RF, batch=batch)
+        else:
+            loss = np.zeros((n_chains, 0)); acc = np.zeros((n_chains, 0), np.uint8); blk = np.zeros((n_chains, 0, 4), np.int32)
+        if return_device:
+            return eng, loss0, loss, acc, blk
+        beds_out = eng.beds.cpu().numpy()
+        res = eng.resampled.cpu().numpy().astype(np.float64)
+    finally:
+        if not return_device:
+            eng.close()
+    out = []
+    for c in range(n_chains):
+        lc = np.concatenate([[loss0[c]], loss[c]])
+        sc = np.concatenate([[0.0], acc[c].astype(np.float64)])
+        bc = np.vstack([np.full((1, 4), np.nan), blk[c].astype(np.float64)])
+        out.append((beds_out[c], lc.copy(), np.zeros(int(n_iter)), lc, sc, res[c], bc))
+    return out
+
+
+def init_lsc_chain_by_instance(param_dict):
+    """Rebuild a chain from a copy of another chain's __dict__ (+ 'rng_seed') (MCMC.py:359-377)."""
+    p = param_dict
+    ch = chain_crf_gpu(p['xx'], p['yy'], p['initial_bed'], p['surf'], p['velx'], p['vely'], p['dhdt'], p['smb'],
+                       p['cond_bed'], p['data_mask'], p['grounded_ice_mask'], p['resolution'])
+    ch.update_in_region = p['update_in_region']
+    ch.region_mask = p['region_mask']
+    ch.sigma_mc = p['sigma_mc']
+    ch.block_type = p['block_type']
+    ch.crf_data_weight = p['crf_data_weight']
+    ch.rng = np.random.default_rng(seed=p['rng_seed'])
+    ch.rng_seed = p['rng_seed']
+    ch.mc_region_mask = p['mc_region_mask']
+    ch.sample_loc = deepcopy(p['sample_loc'])
+    for k in ('rng_mode', 'replay_chunk', 'philox_step', 'philox_batch'):
+        if k in p:
+            setattr(ch, k, p[k])
+    return ch
+
+
+def initiate_RF_by_instance(param_dict):
+    """Rebuild a RandField from a copy of another one's __dict__ (+ 'rng_seed') (MCMC.py:381-398)."""
+    p = param_dict
+    rf = RandField(p['range_min_x'], p['range_max_x'], p['range_min_y'], p['range_max_y'], p['scale_min'],
+                   p['scale_max'], p['nugget_max'], p['model_name'], p['isotropic'], smoothness=p['smoothness'])
+    rf.spectral = p['spectral']
+    rf.min_block_x, rf.min_block_y = p['min_block_x'], p['min_block_y']
+    rf.max_block_x, rf.max_block_y = p['max_block_x'], p['max_block_y']
+    rf.steps = p['steps']
+    rf.pairs = p['pairs']
+    rf.logistic_param = p['logistic_param']
+    rf.max_dist = p['max_dist']
+    rf.resolution = p['resolution']
+    rf.edge_masks = p['edge_masks']
+    rf.rng = np.random.default_rng(seed=p['rng_seed'])
+    return rf
