@@ -89,12 +89,15 @@ int gsm_set_blocks(gsm_handle h, int32_t n_sizes, const int32_t* bh, const int32
  * the cells with region_mask==1; same distribution as the rejection loop of MCMC.py:1253-1261. */
 int gsm_set_centres(gsm_handle h, const int32_t* cells, int32_t n_cells, void* stream);
 
-/* Full-grid residual and loss of every chain's current bed.
- * loss_sum [dev, n_chains*2]: compensated (hi, lo) sum of squared residuals over mc_mask, the state
- * carried between steps;  loss0 [dev, n_chains]: that sum / (2 sigma^2) = loss_cache[0].
+/* Full-grid residual and loss of every chain's current bed: initialises the carried state.
+ * energy   [dev, n_chains*H*W]: r^2 where the cell enters the loss (mc_mask == 1 and r not NaN: nansum
+ *           semantics of MCMC.py:1041), else 0 -- the build's counterpart of the carried residual array
+ *           mc_res (MCMC.py:1189, :1308-1315, :1340);
+ * loss_sum [dev, n_chains*2]: compensated (hi, lo) pair with hi + lo = sum(energy);
+ * loss0    [dev, n_chains] (may be NULL): sum / (2 sigma^2) = loss_cache[0].
  * Replaces: MCMC.py:1189-1195 (Topography.get_mass_conservation_residual, Topography.py:592-600,
  * and chain.loss, MCMC.py:1021-1044). */
-int gsm_init_loss(gsm_handle h, const double* beds, double* loss_sum, double* loss0, void* stream);
+int gsm_init_loss(gsm_handle h, const double* beds, double* energy, double* loss_sum, double* loss0, void* stream);
 
 /* Full-grid residual of chain beds [dev, n_chains*H*W] -> residual [dev, same shape].
  * Replaces: Topography.get_mass_conservation_residual (Topography.py:592-600). */
@@ -106,11 +109,11 @@ int gsm_residual(gsm_handle h, const double* beds, double* residual, void* strea
  *   u        [dev, n_chains*n_steps]      uniform draw of the accept test
  *   fields   [dev]                        masked proposal fields f (bh x bw, row-major) at
  *                                         fields + (c*n_steps+s)*field_stride doubles
- * In/out state: beds, resampled (uint32 counts), loss_sum.  Outputs: loss [n_chains*n_steps]
+ * In/out state: beds, energy, resampled (uint32 counts), loss_sum.  Outputs: loss [n_chains*n_steps]
  * (loss_cache entries), accept [n_chains*n_steps] (0/1).
  * Synchronises the stream before returning (it reports out-of-range device data as GSM_E_DEVICE_DATA).
  * Replaces: the loop body of chain_crf.run, MCMC.py:1263-1360 (torch twin MCMC_gpu.py:385-494). */
-int gsm_run_replay(gsm_handle h, int32_t n_steps, double* beds, uint32_t* resampled, double* loss_sum,
+int gsm_run_replay(gsm_handle h, int32_t n_steps, double* beds, double* energy, uint32_t* resampled, double* loss_sum,
                    const int32_t* size_idx, const int32_t* centre, const double* u,
                    const double* fields, int64_t field_stride,
                    double* loss, uint8_t* accept, void* stream);
@@ -134,7 +137,7 @@ int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, const uint6
  * Replaces: chain_crf.run for a whole shard of chains (MCMC.py:1137-1443) as called from
  * lsc_run_wrapper (largeScaleChain_multiprocessing_GPU.py:194-201). */
 int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int32_t batch, const uint64_t* seeds,
-                   const gsm_rf_params* rf, double* beds, uint32_t* resampled, double* loss_sum,
+                   const gsm_rf_params* rf, double* beds, double* energy, uint32_t* resampled, double* loss_sum,
                    double* loss, uint8_t* accept, int32_t* blocks, void* stream);
 
 /* Average duration in milliseconds of the step kernel / the proposal kernel over the launches made

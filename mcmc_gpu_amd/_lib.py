@@ -97,11 +97,11 @@ def load() -> C.CDLL:
     lib.gsm_set_static.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, dbl, dbl, vp]
     lib.gsm_set_blocks.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), vp, C.POINTER(i64), vp]
     lib.gsm_set_centres.argtypes = [vp, vp, i32, vp]
-    lib.gsm_init_loss.argtypes = [vp, vp, vp, vp, vp]
+    lib.gsm_init_loss.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.gsm_residual.argtypes = [vp, vp, vp, vp]
-    lib.gsm_run_replay.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]
+    lib.gsm_run_replay.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]
     lib.gsm_propose_philox.argtypes = [vp, i32, i64, vp, C.POINTER(RfParams), vp, vp, vp, vp, i64, vp, vp]
-    lib.gsm_run_philox.argtypes = [vp, i32, i64, i32, vp, C.POINTER(RfParams), vp, vp, vp, vp, vp, vp, vp]
+    lib.gsm_run_philox.argtypes = [vp, i32, i64, i32, vp, C.POINTER(RfParams), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsm_enable_timing.argtypes = [vp, i32]
     lib.gsm_last_timing.argtypes = [vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(dbl), C.POINTER(i32)]
     lib.gsm_philox_selftest.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]

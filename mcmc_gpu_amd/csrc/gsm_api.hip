@@ -16,12 +16,16 @@ struct gsm_context {
   double* d_static[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // surf velx vely dhdt smb weight
   uint8_t* d_upd = nullptr;
   uint8_t* d_mc = nullptr;
+  double2 *d_svx = nullptr, *d_svy = nullptr, *d_ds = nullptr;
   StaticFields S{};
   int32_t *d_bh = nullptr, *d_bw = nullptr;
   int64_t* d_mask_off = nullptr;
   double* d_masks = nullptr;
-  double* d_twiddle = nullptr;
-  int32_t* d_tw_off = nullptr;
+  double* d_tables = nullptr;
+  int32_t *d_fy_off = nullptr, *d_g_off = nullptr;
+  int lds_sx = 0, lds_st = 0, lds_x_half = 0, lds_tt = 0, prop_tiles = 0, prop_tiles1 = 0;
+  PropScalars* d_scalars[2] = {nullptr, nullptr};
+  size_t scalars_cap[2] = {0, 0};
   BlockTable B{};
   int tile_cap = 0;
   int32_t* d_centres = nullptr;
@@ -99,12 +103,17 @@ extern "C" int gsm_destroy(gsm_handle h) {
   for (auto& p : h->d_static) if (p) hipFree(p);
   if (h->d_upd) hipFree(h->d_upd);
   if (h->d_mc) hipFree(h->d_mc);
+  if (h->d_svx) hipFree(h->d_svx);
+  if (h->d_svy) hipFree(h->d_svy);
+  if (h->d_ds) hipFree(h->d_ds);
   if (h->d_bh) hipFree(h->d_bh);
   if (h->d_bw) hipFree(h->d_bw);
   if (h->d_mask_off) hipFree(h->d_mask_off);
   if (h->d_masks) hipFree(h->d_masks);
-  if (h->d_twiddle) hipFree(h->d_twiddle);
-  if (h->d_tw_off) hipFree(h->d_tw_off);
+  if (h->d_tables) hipFree(h->d_tables);
+  if (h->d_fy_off) hipFree(h->d_fy_off);
+  if (h->d_g_off) hipFree(h->d_g_off);
+  for (auto& p : h->d_scalars) if (p) hipFree(p);
   if (h->d_centres) hipFree(h->d_centres);
   if (h->d_err) hipFree(h->d_err);
   free_scratch(h);
@@ -143,7 +152,6 @@ extern "C" int gsm_set_static(gsm_handle h, const double* surf, const double* ve
   }
   HIPCHK(h, dup_device(&h->d_upd, update_mask, n, st));
   HIPCHK(h, dup_device(&h->d_mc, mc_mask, n, st));
-  HIPCHK(h, hipStreamSynchronize(st));
   StaticFields& S = h->S;
   S.surf = h->d_static[0]; S.velx = h->d_static[1]; S.vely = h->d_static[2];
   S.dhdt = h->d_static[3]; S.smb = h->d_static[4]; S.weight = h->d_static[5];
@@ -151,7 +159,25 @@ extern "C" int gsm_set_static(gsm_handle h, const double* surf, const double* ve
   S.H = h->H; S.W = h->W;
   S.res = resolution;
   S.two_res = 2.0 * resolution;
+  S.rcp_res = 1.0 / S.res;
+  S.rcp_two_res = 1.0 / S.two_res;
+  // exact_div() needs a correctly rounded reciprocal of a divisor whose significand is not all ones and
+  // quotients far from the exponent limits; anything else takes the IEEE division path.
+  {
+    uint64_t bits;
+    memcpy(&bits, &S.res, sizeof(bits));
+    const bool all_ones = (bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull;
+    S.fast_div = (!all_ones && S.res > 1e-100 && S.res < 1e100) ? 1 : 0;
+  }
   S.two_sigma2 = 2 * (sigma_mc * sigma_mc);
+  if (!h->d_svx) {
+    HIPCHK(h, hipMalloc(&h->d_svx, n * sizeof(double2)));
+    HIPCHK(h, hipMalloc(&h->d_svy, n * sizeof(double2)));
+    HIPCHK(h, hipMalloc(&h->d_ds, n * sizeof(double2)));
+  }
+  HIPCHK(h, launch_pack_static(S, h->d_svx, h->d_svy, h->d_ds, st));
+  S.svx = h->d_svx; S.svy = h->d_svy; S.ds = h->d_ds;
+  HIPCHK(h, hipStreamSynchronize(st));
   h->have_static = true;
   return GSM_OK;
 }
@@ -185,22 +211,59 @@ extern "C" int gsm_set_blocks(gsm_handle h, int32_t n_sizes, const int32_t* bh, 
     if (h->d_masks) { hipFree(h->d_masks); h->d_masks = nullptr; }
     if (h->d_mask_off) { hipFree(h->d_mask_off); h->d_mask_off = nullptr; }
   }
-  // twiddle tables: for each distinct length n, (cos, sin)(2 pi m / n), m = 0..n-1
+  // DFT operand tables of the proposal kernel, one set per distinct block height / width (zero padded to the
+  // MFMA tile grid; dimension formulas mirror propose_kernel):
+  //   height n: FC[ky][y] = cos(2 pi ky y / n), FS = sin(...), each [K1 = ceil4(n)][N1 = ceil16(n)]
+  //   width  n: G[k][x]        = c_k cos(2 pi k x / n)      k <  ncol = n/2+1   (c_k = 1 for k in {0, n/2}, else 2)
+  //             G[Kc + k][x]   = -c_k sin(2 pi k x / n)                          Kc = ceil4(ncol), [2 Kc][N2 = ceil16(n)]
   const int max_len = std::max(max_bh, max_bw);
-  std::vector<int32_t> off(max_len + 1, -1);
-  std::vector<double> tw;
-  for (int i = 0; i < n_sizes; ++i)
-    for (int n : {bh[i], bw[i]})
-      if (off[n] < 0) {
-        off[n] = (int32_t)tw.size();
-        for (int m = 0; m < n; ++m) {
-          const double ang = 2.0 * M_PI * (double)m / (double)n;
-          tw.push_back(cos(ang));
-          tw.push_back(sin(ang));
+  std::vector<int32_t> fy_off(max_len + 1, -1), g_off(max_len + 1, -1);
+  std::vector<double> tb;
+  int k1max = 0, n1max = 0, m1max = 0, k2max = 0, tiles_max = 0;
+  for (int i = 0; i < n_sizes; ++i) {
+    const int n = bh[i];
+    const int K1 = (n + 3) & ~3, N1 = (n + 15) & ~15;
+    k1max = std::max(k1max, K1); n1max = std::max(n1max, N1);
+    if (fy_off[n] < 0) {
+      fy_off[n] = (int32_t)tb.size();
+      tb.resize(tb.size() + (size_t)2 * K1 * N1, 0.0);
+      double* FC = tb.data() + fy_off[n];
+      double* FS = FC + (size_t)K1 * N1;
+      for (int ky = 0; ky < n; ++ky)
+        for (int y = 0; y < n; ++y) {
+          const double ang = 2.0 * M_PI * (double)(((int64_t)ky * y) % n) / (double)n;
+          FC[ky * N1 + y] = cos(ang);
+          FS[ky * N1 + y] = sin(ang);
+        }
+    }
+    const int w = bw[i];
+    const int ncol = w / 2 + 1, Kc = (ncol + 3) & ~3, N2 = (w + 15) & ~15, M1 = (ncol + 15) & ~15;
+    m1max = std::max(m1max, M1); k2max = std::max(k2max, 2 * Kc);
+    tiles_max = std::max(tiles_max, (N1 / 16) * (N2 / 16));
+    h->prop_tiles1 = std::max(h->prop_tiles1, (M1 / 16) * (N1 / 16));
+    if (g_off[w] < 0) {
+      g_off[w] = (int32_t)tb.size();
+      tb.resize(tb.size() + (size_t)2 * Kc * N2, 0.0);
+      double* G = tb.data() + g_off[w];
+      for (int k = 0; k < ncol; ++k) {
+        const double ck = (k == 0 || k == w / 2) ? 1.0 : 2.0;
+        for (int x = 0; x < w; ++x) {
+          const double ang = 2.0 * M_PI * (double)(((int64_t)k * x) % w) / (double)w;
+          G[k * N2 + x] = ck * cos(ang);
+          G[(Kc + k) * N2 + x] = -ck * sin(ang);
         }
       }
-  HIPCHK(h, dup_device(&h->d_twiddle, tw.data(), tw.size(), st));
-  HIPCHK(h, dup_device(&h->d_tw_off, off.data(), off.size(), st));
+    }
+  }
+  auto stride16mod32 = [](int v) { int s = v; while ((s & 31) != 16) ++s; return s; };
+  h->lds_sx = stride16mod32(m1max);
+  h->lds_st = stride16mod32(n1max);
+  h->lds_x_half = k1max * h->lds_sx;
+  h->lds_tt = k2max * h->lds_st;
+  h->prop_tiles = tiles_max;
+  HIPCHK(h, dup_device(&h->d_tables, tb.data(), tb.size(), st));
+  HIPCHK(h, dup_device(&h->d_fy_off, fy_off.data(), fy_off.size(), st));
+  HIPCHK(h, dup_device(&h->d_g_off, g_off.data(), g_off.size(), st));
   HIPCHK(h, hipStreamSynchronize(st));
   h->B.bh = h->d_bh; h->B.bw = h->d_bw; h->B.masks = h->d_masks; h->B.mask_off = h->d_mask_off;
   h->B.n_sizes = n_sizes; h->B.max_bh = max_bh; h->B.max_bw = max_bw;
@@ -223,12 +286,12 @@ extern "C" int gsm_set_centres(gsm_handle h, const int32_t* cells, int32_t n_cel
   return GSM_OK;
 }
 
-extern "C" int gsm_init_loss(gsm_handle h, const double* beds, double* loss_sum, double* loss0, void* stream) {
+extern "C" int gsm_init_loss(gsm_handle h, const double* beds, double* energy, double* loss_sum, double* loss0, void* stream) {
   if (!h) return GSM_E_ARG;
   if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_init_loss: call gsm_set_static first");
-  if (!beds || !loss_sum) return fail(h, GSM_E_ARG, "gsm_init_loss: NULL pointer");
+  if (!beds || !energy || !loss_sum) return fail(h, GSM_E_ARG, "gsm_init_loss: NULL pointer");
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, launch_init_loss(h->S, h->n_chains, beds, loss_sum, loss0, (hipStream_t)stream));
+  HIPCHK(h, launch_init_loss(h->S, h->n_chains, beds, energy, loss_sum, loss0, (hipStream_t)stream));
   return GSM_OK;
 }
 
@@ -253,7 +316,7 @@ static int check_device_flag(gsm_handle h, hipStream_t st, const char* who) {
   return GSM_OK;
 }
 
-extern "C" int gsm_run_replay(gsm_handle h, int32_t n_steps, double* beds, uint32_t* resampled, double* loss_sum,
+extern "C" int gsm_run_replay(gsm_handle h, int32_t n_steps, double* beds, double* energy, uint32_t* resampled, double* loss_sum,
                               const int32_t* size_idx, const int32_t* centre, const double* u,
                               const double* fields, int64_t field_stride, double* loss, uint8_t* accept,
                               void* stream) {
@@ -261,7 +324,7 @@ extern "C" int gsm_run_replay(gsm_handle h, int32_t n_steps, double* beds, uint3
   if (!h->have_static || !h->have_blocks) return fail(h, GSM_E_STATE, "gsm_run_replay: call gsm_set_static and gsm_set_blocks first");
   if (n_steps < 0) return fail(h, GSM_E_ARG, "gsm_run_replay: n_steps < 0");
   if (n_steps == 0) return GSM_OK;
-  if (!beds || !resampled || !loss_sum || !size_idx || !centre || !u || !fields || !loss || !accept)
+  if (!beds || !energy || !resampled || !loss_sum || !size_idx || !centre || !u || !fields || !loss || !accept)
     return fail(h, GSM_E_ARG, "gsm_run_replay: NULL pointer");
   if (field_stride < (int64_t)h->B.max_bh * h->B.max_bw)
     return fail(h, GSM_E_ARG, "gsm_run_replay: field_stride smaller than the largest block");
@@ -270,7 +333,7 @@ extern "C" int gsm_run_replay(gsm_handle h, int32_t n_steps, double* beds, uint3
   StepArgs a{};
   a.S = h->S; a.B = h->B;
   a.n_chains = h->n_chains; a.n_steps = n_steps; a.tile_cap = h->tile_cap;
-  a.beds = beds; a.resampled = resampled; a.loss_sum = loss_sum;
+  a.beds = beds; a.energy = energy; a.resampled = resampled; a.loss_sum = loss_sum;
   a.size_idx = size_idx; a.centre = centre; a.u = u; a.fields = fields; a.field_stride = field_stride;
   a.loss = loss; a.accept = accept; a.blocks = nullptr;
   a.rec_stride = n_steps; a.rec_offset = 0; a.in_stride = n_steps;
@@ -287,8 +350,18 @@ static int check_propose_ready(gsm_handle h, const gsm_rf_params* rf, const char
   if (!(rf->resolution > 0.0)) return fail(h, GSM_E_ARG, std::string(who) + ": rf.resolution must be > 0");
   if (rf->model == GSM_MODEL_MATERN && !(rf->smoothness > 0.0))
     return fail(h, GSM_E_ARG, std::string(who) + ": Matern needs smoothness > 0");
-  const size_t lds = ((size_t)4 * h->B.max_bh * (h->B.max_bw / 2 + 1) + 2 * h->B.max_bh + 2 * h->B.max_bw + 8) * 8;
-  if (lds > 160 * 1024) return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": block too large for the proposal kernel's LDS");
+  const size_t lds = ((size_t)std::max(2 * h->lds_x_half, h->lds_tt) + 64) * 8;
+  if (lds > 160 * 1024 || h->prop_tiles > propose_max_tiles_per_wave() * propose_waves() ||
+      h->prop_tiles1 > propose_max_tiles1_per_wave() * propose_waves())
+    return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": block too large for the proposal kernel (LDS / accumulator tiles)");
+  return GSM_OK;
+}
+
+static int ensure_scalars(gsm_handle h, int slot, size_t recs) {
+  if (h->scalars_cap[slot] >= recs) return GSM_OK;
+  if (h->d_scalars[slot]) { hipFree(h->d_scalars[slot]); h->d_scalars[slot] = nullptr; h->scalars_cap[slot] = 0; }
+  HIPCHK(h, hipMalloc(&h->d_scalars[slot], recs * sizeof(PropScalars)));
+  h->scalars_cap[slot] = recs;
   return GSM_OK;
 }
 
@@ -297,7 +370,9 @@ static ProposeArgs make_propose(gsm_handle h, const gsm_rf_params* rf, int n_ste
   p.B = h->B; p.rf = *rf; p.H = h->H; p.W = h->W;
   p.n_chains = h->n_chains; p.n_steps = n_steps; p.step0 = step0; p.seeds = seeds;
   p.centres = h->d_centres; p.n_centres = h->n_centres;
-  p.twiddle = h->d_twiddle; p.tw_off = h->d_tw_off;
+  p.tables = h->d_tables; p.fy_off = h->d_fy_off; p.g_off = h->d_g_off;
+  p.lds_sx = h->lds_sx; p.lds_st = h->lds_st; p.lds_x_half = h->lds_x_half; p.lds_tt = h->lds_tt;
+  p.lds_main = std::max(2 * h->lds_x_half, h->lds_tt);
   return p;
 }
 
@@ -311,9 +386,10 @@ extern "C" int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, 
   if (!seeds || !size_idx || !centre || !u || !fields) return fail(h, GSM_E_ARG, "gsm_propose_philox: NULL pointer");
   if (field_stride < (int64_t)h->B.max_bh * h->B.max_bw) return fail(h, GSM_E_ARG, "gsm_propose_philox: field_stride too small");
   HIPCHK(h, hipSetDevice(h->device));
+  { int rc2 = ensure_scalars(h, 0, (size_t)h->n_chains * n_steps); if (rc2) return rc2; }
   ProposeArgs p = make_propose(h, rf, n_steps, step0, seeds);
   p.size_idx = size_idx; p.centre = centre; p.u = u; p.fields = fields; p.field_stride = field_stride;
-  p.rf_scalars = rf_scalars;
+  p.rf_scalars = rf_scalars; p.scalars = h->d_scalars[0];
   HIPCHK(h, launch_propose(p, (hipStream_t)stream));
   return GSM_OK;
 }
@@ -334,7 +410,7 @@ extern "C" int gsm_last_timing(gsm_handle h, double* step_ms, int32_t* step_laun
 }
 
 extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int32_t batch, const uint64_t* seeds,
-                              const gsm_rf_params* rf, double* beds, uint32_t* resampled, double* loss_sum,
+                              const gsm_rf_params* rf, double* beds, double* energy, uint32_t* resampled, double* loss_sum,
                               double* loss, uint8_t* accept, int32_t* blocks, void* stream) {
   if (!h) return GSM_E_ARG;
   if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_run_philox: call gsm_set_static first");
@@ -343,7 +419,7 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
   if (n_steps < 0) return fail(h, GSM_E_ARG, "gsm_run_philox: n_steps < 0");
   if (n_steps == 0) return GSM_OK;
   if (batch < 1 || batch > 65535) return fail(h, GSM_E_ARG, "gsm_run_philox: batch must be in [1, 65535]");
-  if (!seeds || !beds || !resampled || !loss_sum || !loss || !accept) return fail(h, GSM_E_ARG, "gsm_run_philox: NULL pointer");
+  if (!seeds || !beds || !energy || !resampled || !loss_sum || !loss || !accept) return fail(h, GSM_E_ARG, "gsm_run_philox: NULL pointer");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(h, hipSetDevice(h->device));
   if (batch > n_steps) batch = n_steps;
@@ -358,6 +434,7 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
     HIPCHK(h, hipMalloc(&s.fields, recs * (size_t)h->field_stride * sizeof(double)));
     s.recs = recs;
   }
+  for (int i = 0; i < 2; ++i) { int rc2 = ensure_scalars(h, i, recs); if (rc2) return rc2; }
   if (!h->aux) HIPCHK(h, hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
   for (int i = 0; i < 2; ++i) {
     if (!h->ev_prop[i]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_prop[i], hipEventDisableTiming));
@@ -379,7 +456,7 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
     if (k >= 2) HIPCHK(h, hipStreamWaitEvent(h->aux, h->ev_step[k & 1], 0));  // buffer free again
     ProposeArgs p = make_propose(h, rf, nb, step0 + (int64_t)k * batch, seeds);
     p.size_idx = s.size_idx; p.centre = s.centre; p.u = s.u; p.fields = s.fields; p.field_stride = h->field_stride;
-    p.rf_scalars = nullptr;
+    p.rf_scalars = nullptr; p.scalars = h->d_scalars[k & 1];
     if (h->timing) HIPCHK(h, hipEventRecord(tev[4 * k], h->aux));
     HIPCHK(h, launch_propose(p, h->aux));
     if (h->timing) HIPCHK(h, hipEventRecord(tev[4 * k + 1], h->aux));
@@ -397,7 +474,7 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
     StepArgs a{};
     a.S = h->S; a.B = h->B;
     a.n_chains = h->n_chains; a.n_steps = nb; a.tile_cap = h->tile_cap;
-    a.beds = beds; a.resampled = resampled; a.loss_sum = loss_sum;
+    a.beds = beds; a.energy = energy; a.resampled = resampled; a.loss_sum = loss_sum;
     a.size_idx = s.size_idx; a.centre = s.centre; a.u = s.u; a.fields = s.fields; a.field_stride = h->field_stride;
     a.loss = loss; a.accept = accept; a.blocks = blocks;
     a.rec_stride = n_steps; a.rec_offset = (int64_t)k * batch; a.in_stride = nb;

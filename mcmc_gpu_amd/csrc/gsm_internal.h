@@ -18,9 +18,16 @@ struct StaticFields {
   const double* weight;   // nullptr => block_type 'RF'
   const uint8_t* upd;     // update / guard / resampled mask
   const uint8_t* mc;      // loss mask
+  // packed copies for the step kernel's stencil: one 16-byte load per neighbour
+  const double2* svx;     // (surf, velx)
+  const double2* svy;     // (surf, vely)
+  const double2* ds;      // (dhdt, smb)
   int H, W;
   double res;             // grid spacing h
   double two_res;         // 2.0 * h  (np.gradient interior denominator)
+  double rcp_res;         // RN(1/h), RN(1/(2h)): used when fast_div
+  double rcp_two_res;
+  int fast_div;           // 1: x/h as fma-corrected reciprocal multiply (bit-identical to IEEE division)
   double two_sigma2;      // 2 * sigma_mc**2
 };
 
@@ -39,6 +46,7 @@ struct StepArgs {
   int n_chains, n_steps;
   int tile_cap;           // doubles available for the LDS tile
   double* beds;
+  double* energy;         // [n_chains][H][W] masked squared residual of the current bed (0 where not counted)
   uint32_t* resampled;
   double* loss_sum;       // [n_chains][2]
   const int32_t* size_idx;
@@ -53,6 +61,13 @@ struct StepArgs {
   int64_t rec_offset;     // first record of this launch within a chain's row
   int64_t in_stride;      // records per chain in the proposal arrays (size_idx, centre, u, fields)
   int32_t* err_flag;      // device int, set non-zero on bad device data
+};
+
+// per-proposal scalars written by propose_scalars_kernel and read (uniformly) by propose_kernel
+struct PropScalars {
+  double scale, nug, range_x, range_y, u;
+  double aa, m_const, m_kappa;   // spectral-amplitude parameters (MCMC.py:209-239)
+  int32_t si, row, col, pad;
 };
 
 struct ProposeArgs {
@@ -70,16 +85,28 @@ struct ProposeArgs {
   double* fields;
   int64_t field_stride;
   double* rf_scalars;      // optional
-  const double* twiddle;   // device: cos/sin tables per distinct length (see proposal_kernel.hip)
-  const int32_t* tw_off;   // device: offset (doubles) of the table of length n, indexed by n (0..max)
+  // DFT operand tables (device), built by gsm_set_blocks; see proposal_kernel.hip for the shapes
+  const double* tables;
+  const int32_t* fy_off;   // indexed by block height n: offset of [cos | sin](2 pi ky y / n), each [K1][N1]
+  const int32_t* g_off;    // indexed by block width n: offset of the folded c2r table G, [K2][N2]
+  int lds_sx, lds_st;      // LDS row strides of X and T^T (== 16 mod 32 doubles: conflict-free fragment reads)
+  int lds_x_half;          // doubles per X plane (re or im)
+  int lds_tt;              // doubles of T^T
+  int lds_main;            // max(2 * lds_x_half, lds_tt): T^T overlays X
+  PropScalars* scalars;    // device scratch, n_chains * n_steps records
+  int dbg;                 // diagnostics only (GSM_PROPOSE_DBG): bit0 cheap coefficients, bit1 skip stage 1, bit2 skip stage 2
 };
 
 // launchers (defined next to their kernels)
 hipError_t launch_step(const StepArgs& a, hipStream_t st);
-hipError_t launch_init_loss(const StaticFields& S, int n_chains, const double* beds, double* loss_sum,
-                            double* loss0, hipStream_t st);
+hipError_t launch_init_loss(const StaticFields& S, int n_chains, const double* beds, double* energy,
+                            double* loss_sum, double* loss0, hipStream_t st);
+hipError_t launch_pack_static(const StaticFields& S, double2* svx, double2* svy, double2* ds, hipStream_t st);
 hipError_t launch_residual(const StaticFields& S, int n_chains, const double* beds, double* out, hipStream_t st);
 hipError_t launch_propose(const ProposeArgs& a, hipStream_t st);
+int propose_max_tiles_per_wave();
+int propose_max_tiles1_per_wave();
+int propose_waves();
 size_t step_lds_bytes(int tile_cap);
 
 }  // namespace gsm

@@ -4,8 +4,8 @@
 // :176-254), the block-centre rejection loop (MCMC.py:1253-1261) and rng.random() (MCMC.py:1336) with
 // a counter-based generator.  The draws are different numbers than NumPy's PCG64 stream gives, so this
 // path is checked (a) value-for-value against the CPU restatement of THIS algorithm
-// (oracle/philox_oracle.py, <=1e-10) and (b) in distribution against the reference's spectral
-// proposal (covariance, accept rate).
+// (oracle/philox_oracle.py, <=1e-10 of the field scale) and (b) in distribution against the reference's
+// spectral proposal (covariance, accept rate).
 //
 // Same distribution, half the work.  The reference takes Re(ifft2((N1 + i N2) * sqrt(S))) with two
 // full planes of normals.  The real part of an inverse DFT is the inverse DFT of the Hermitian part of
@@ -14,16 +14,28 @@
 // the kernel draws the half plane kx in [0, bw/2] directly -- bh*bw normals instead of 2*bh*bw -- and
 // runs a complex-to-real inverse DFT: columns first (complex, bw/2+1 of them), then rows (real output).
 //
-// v1: both DFT stages are plain fp64 FMA loops over LDS-resident data and twiddle tables.
+// The two DFT stages are dense fp64 matrix products on the matrix cores (v_mfma_f64_16x16x4_f64):
+//   stage 1   T^T[kx][y]  = sum_ky X[ky][kx] * exp(+2 pi i ky y / bh)      A = X^T (LDS), B = cos/sin table (L2)
+//   stage 2   field[y][x] = sum_k2 T^T[k2][y] * G[k2][x]                    A = T^T (LDS), B = G table (L2)
+// with G rows = c_k cos(2 pi k x / bw) for the real rows and -c_k sin(...) for the imaginary rows (c_k = 1 for
+// k in {0, bw/2}, else 2: the folded Hermitian half).  The field never touches LDS: it stays in the MFMA
+// accumulators through the standardisation and goes straight to HBM.
+//
+// MFMA operand maps used here (16x16x4 f64): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// C/D reg q: row = (lane >> 4) + 4 q, col = lane & 15.
 
 #include "gsm_internal.h"
 #include "philox.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace gsm {
 
 constexpr int kPBlock = 512;
 constexpr int kPWaves = kPBlock / 64;
+constexpr int kMaxT1 = 2;   // stage-1 output tiles per wave
+constexpr int kMaxT2 = 4;   // stage-2 output tiles per wave
+typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t pmagic(uint32_t d) { return (uint32_t)(0xFFFFFFFFu / d) + 1u; }
 
@@ -51,185 +63,292 @@ __device__ __forceinline__ double block_sum(double v, double* red, int tid) {
   return t;
 }
 
-// frequency magnitude^2 helper: 2*pi*fftfreq(n, d=res)[k]
+// 2*pi*fftfreq(n, d=res)[k]
 __device__ __forceinline__ double wavenumber(int k, int n, double res) {
   const int kk = (k < (n + 1) / 2) ? k : k - n;  // numpy fftfreq ordering (n even: k=n/2 -> -n/2)
   return ((double)kk / ((double)n * res)) * 2.0 * M_PI;
 }
 
-__global__ __launch_bounds__(kPBlock) void propose_kernel(const ProposeArgs a, const int cap_half) {
-  extern __shared__ double plds[];
-  // layout: Xr | Xi | Tr | Ti (cap_half each) | cy sy (max_bh each) | cx sx (max_bw each) | red
-  double* Xr = plds;
-  double* Xi = Xr + cap_half;
-  double* Tr = Xi + cap_half;
-  double* Ti = Tr + cap_half;
-  double* cy = Ti + cap_half;
-  double* sy = cy + a.B.max_bh;
-  double* cx = sy + a.B.max_bh;
-  double* sx = cx + a.B.max_bw;
-  double* red = sx + a.B.max_bw;
-  double* fieldv = Xr;  // bh*bw doubles <= 2*cap_half, overlays X once stage 1 is done
+// ---------------------------------------------------------------------------------------------------
+// per-proposal scalars: one thread per (chain, step).  Draw layout (stream kStreamScalars):
+//   idx 0: {scale u, nugget u}   idx 1: {range_x u, range_y u}   idx 2: {accept u, centre word}   idx 3: {size word}
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void propose_scalars_kernel(const ProposeArgs a) {
+  const int64_t rec = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (rec >= (int64_t)a.n_chains * a.n_steps) return;
+  const int chain = (int)(rec / a.n_steps), s = (int)(rec - (int64_t)chain * a.n_steps);
+  const int64_t step = a.step0 + s;
+  const uint64_t seed = a.seeds[chain];
+  const gsm_rf_params& P = a.rf;
+  const u32x4 d0 = philox_draw(seed, step, kStreamScalars, 0);
+  const u32x4 d1 = philox_draw(seed, step, kStreamScalars, 1);
+  const u32x4 d2 = philox_draw(seed, step, kStreamScalars, 2);
+  const u32x4 d3 = philox_draw(seed, step, kStreamScalars, 3);
+  PropScalars r;
+  r.si = (int)__umulhi(d3.x, (uint32_t)a.B.n_sizes);
+  r.scale = (P.scale_min + (P.scale_max - P.scale_min) * u01_from(d0.x, d0.y)) / 3.0;
+  r.nug = 0.0 + (P.nugget_max - 0.0) * u01_from(d0.z, d0.w);
+  r.range_x = P.range_min_x + (P.range_max_x - P.range_min_x) * u01_from(d1.x, d1.y);
+  r.range_y = P.isotropic ? r.range_x : P.range_min_y + (P.range_max_y - P.range_min_y) * u01_from(d1.z, d1.w);
+  r.u = u01_from(d2.x, d2.y);
+  const uint64_t cw = ((uint64_t)d2.w << 32) | d2.z;
+  const int cell = a.centres[(int)__umul64hi(cw, (uint64_t)a.n_centres)];
+  r.row = cell / a.W;
+  r.col = cell - r.row * a.W;
+  // spectral amplitude parameters (MCMC.py:209-239)
+  double lx, ly;
+  if (P.model == GSM_MODEL_GAUSSIAN) { lx = r.range_x / sqrt(3.0); ly = r.range_y / sqrt(3.0); }
+  else if (P.model == GSM_MODEL_EXPONENTIAL) { lx = r.range_x / 3.0; ly = r.range_y / 3.0; }
+  else { lx = r.range_x / 2.0; ly = r.range_y / 2.0; }
+  r.aa = sqrt(lx * ly);
+  r.m_const = 0.0; r.m_kappa = 0.0;
+  if (P.model == GSM_MODEL_MATERN) {
+    const double nu = (P.smoothness != 0.0) ? P.smoothness : 1.0;
+    r.m_const = (4.0 * M_PI * tgamma(nu + 1.0) * pow(2.0 * nu, nu)) / (tgamma(nu) * pow(r.aa, 2.0 * nu));
+    r.m_kappa = 2.0 * nu / (r.aa * r.aa);
+  }
+  r.pad = 0;
+  a.scalars[rec] = r;
+  a.size_idx[rec] = r.si;
+  a.centre[2 * rec] = r.row;
+  a.centre[2 * rec + 1] = r.col;
+  a.u[rec] = r.u;
+  if (a.rf_scalars) {
+    a.rf_scalars[4 * rec] = r.scale;
+    a.rf_scalars[4 * rec + 1] = r.nug;
+    a.rf_scalars[4 * rec + 2] = r.range_x;
+    a.rf_scalars[4 * rec + 3] = r.range_y;
+  }
+}
 
-  const int tid = threadIdx.x;
+// sqrt(S(k)) of MCMC.py:227-239, :244
+__device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const PropScalars& sc, int ky, int kx, int bh, int bw) {
+  const double kxv = wavenumber(kx, bw, P.resolution), kyv = wavenumber(ky, bh, P.resolution);
+  const double k = sqrt(kxv * kxv + kyv * kyv) + 1e-10;
+  double Sp;
+  if (P.model == GSM_MODEL_GAUSSIAN) { const double ak = sc.aa * k; Sp = exp(-0.5 * (ak * ak)); }
+  else if (P.model == GSM_MODEL_EXPONENTIAL) { const double ak = sc.aa * k; Sp = exp(-1.5 * log(1.0 + ak * ak)); }
+  else {
+    const double nu = (P.smoothness != 0.0) ? P.smoothness : 1.0;
+    Sp = sc.m_const * exp((-nu - 1.0) * log(sc.m_kappa + 4.0 * M_PI * (k * k)));
+  }
+  return sqrt(Sp);
+}
+
+__global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a) {
+  extern __shared__ double plds[];
+  const int SX = a.lds_sx, ST = a.lds_st;
+  double* Xr = plds;                       // [K1max][SX]
+  double* Xi = Xr + a.lds_x_half;          // [K1max][SX]
+  double* TT = plds;                       // [K2max][ST]  -- overlays X once stage 1 has consumed it
+  double* red = plds + a.lds_main;         // [kPWaves]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = blockIdx.x, chain = blockIdx.y;
   const int64_t step = a.step0 + s;
   const uint64_t seed = a.seeds[chain];
   const int64_t rec = (int64_t)chain * a.n_steps + s;
   const gsm_rf_params& P = a.rf;
-
-  // ---- scalar draws (every thread computes the same values) -----------------------------------
-  const u32x4 d0 = philox_draw(seed, step, kStreamScalars, 0);
-  const u32x4 d1 = philox_draw(seed, step, kStreamScalars, 1);
-  const u32x4 d2 = philox_draw(seed, step, kStreamScalars, 2);
-  const u32x4 d3 = philox_draw(seed, step, kStreamScalars, 3);
-  const int si = (int)__umulhi(d3.x, (uint32_t)a.B.n_sizes);
-  const double scale = (P.scale_min + (P.scale_max - P.scale_min) * u01_from(d0.x, d0.y)) / 3.0;
-  const double nug = 0.0 + (P.nugget_max - 0.0) * u01_from(d0.z, d0.w);
-  const double range_x = P.range_min_x + (P.range_max_x - P.range_min_x) * u01_from(d1.x, d1.y);
-  const double range_y = P.isotropic ? range_x : P.range_min_y + (P.range_max_y - P.range_min_y) * u01_from(d1.z, d1.w);
-  const double u_acc = u01_from(d2.x, d2.y);
-  const uint64_t cw = ((uint64_t)d2.w << 32) | d2.z;
-  const int cell = a.centres[(int)__umul64hi(cw, (uint64_t)a.n_centres)];
+  const PropScalars sc = a.scalars[rec];
+  const int si = sc.si;
   const int bh = a.B.bh[si], bw = a.B.bw[si];
   const int ncol = bw / 2 + 1;
-  if (tid == 0) {
-    a.size_idx[rec] = si;
-    a.centre[2 * rec] = cell / a.W;
-    a.centre[2 * rec + 1] = cell - (cell / a.W) * a.W;
-    a.u[rec] = u_acc;
-    if (a.rf_scalars) {
-      a.rf_scalars[4 * rec] = scale;
-      a.rf_scalars[4 * rec + 1] = nug;
-      a.rf_scalars[4 * rec + 2] = range_x;
-      a.rf_scalars[4 * rec + 3] = range_y;
-    }
-  }
 
-  // ---- twiddle tables of the two lengths -> LDS ------------------------------------------------
+  // padded GEMM dimensions (host builds the tables with the same formulas)
+  const int K1 = (bh + 3) & ~3;            // stage-1 K  (ky)
+  const int N1 = (bh + 15) & ~15;          // stage-1 N  (y)   = stage-2 M
+  const int M1 = (ncol + 15) & ~15;        // stage-1 M  (kx)
+  const int Kc = (ncol + 3) & ~3;          // rows per (re | im) half of T^T
+  const int K2 = 2 * Kc;                   // stage-2 K
+  const int N2 = (bw + 15) & ~15;          // stage-2 N  (x)
+
+  // ---- Hermitian half-plane coefficients X[ky][kx] -> LDS ---------------------------------------
+  // zero the padding (rows bh..K1, columns ncol..M1), then one work item per (ky <= bh/2, kx): the spectral
+  // amplitude is shared by rows ky and bh-ky, and on the two self-conjugate columns those rows are a
+  // conjugate pair built from the same two draws.
   {
-    const double* ty = a.twiddle + a.tw_off[bh];
-    const double* tx = a.twiddle + a.tw_off[bw];
-    for (int i = tid; i < bh; i += kPBlock) { cy[i] = ty[2 * i]; sy[i] = ty[2 * i + 1]; }
-    for (int i = tid; i < bw; i += kPBlock) { cx[i] = tx[2 * i]; sx[i] = tx[2 * i + 1]; }
-  }
-
-  // ---- spectral amplitude parameters (MCMC.py:209-239) ----------------------------------------
-  double lx, ly;
-  if (P.model == GSM_MODEL_GAUSSIAN) { lx = range_x / sqrt(3.0); ly = range_y / sqrt(3.0); }
-  else if (P.model == GSM_MODEL_EXPONENTIAL) { lx = range_x / 3.0; ly = range_y / 3.0; }
-  else { lx = range_x / 2.0; ly = range_y / 2.0; }
-  const double aa = sqrt(lx * ly);
-  const double nu = (P.smoothness != 0.0) ? P.smoothness : 1.0;
-  double m_const = 0.0, m_kappa = 0.0;
-  if (P.model == GSM_MODEL_MATERN) {
-    m_const = (4.0 * M_PI * tgamma(nu + 1.0) * pow(2.0 * nu, nu)) / (tgamma(nu) * pow(aa, 2.0 * nu));
-    m_kappa = 2.0 * nu / (aa * aa);
-  }
-
-  // ---- Hermitian half-plane coefficients --------------------------------------------------------
-  const int nhalf = bh * ncol;
-  const uint32_t m_ncol = pmagic((uint32_t)ncol);
-  for (int i = tid; i < nhalf; i += kPBlock) {
-    const int ky = (int)__umulhi((uint32_t)i, m_ncol);
-    const int kx = i - ky * ncol;
-    const double kxv = wavenumber(kx, bw, P.resolution), kyv = wavenumber(ky, bh, P.resolution);
-    const double k = sqrt(kxv * kxv + kyv * kyv) + 1e-10;
-    double Sp;
-    if (P.model == GSM_MODEL_GAUSSIAN) { const double ak = aa * k; Sp = exp(-0.5 * (ak * ak)); }
-    else if (P.model == GSM_MODEL_EXPONENTIAL) { const double ak = aa * k; Sp = 1.0 / pow(1.0 + ak * ak, 1.5); }
-    else Sp = m_const * pow(m_kappa + 4.0 * M_PI * (k * k), -nu - 1.0);
-    const double amp = sqrt(Sp);
-    double g1, g2;
-    normals2(seed, step, kStreamSpectrum, (uint32_t)i, g1, g2);
-    double xr, xi;
-    if (kx > 0 && kx < bw / 2) {
-      xr = amp * (g1 * M_SQRT1_2);
-      xi = amp * (g2 * M_SQRT1_2);
-    } else {
-      const int kyc = (ky == 0) ? 0 : bh - ky;
-      double h1, h2;
-      normals2(seed, step, kStreamSpectrum, (uint32_t)(kyc * ncol + kx), h1, h2);
-      xr = amp * (0.5 * (g1 + h1));
-      xi = amp * (0.5 * (g2 - h2));
+    const int npad = K1 * M1;
+    const uint32_t m_m1 = pmagic((uint32_t)M1);
+    for (int i = tid; i < npad; i += kPBlock) {
+      const int ky = (int)__umulhi((uint32_t)i, m_m1);
+      const int kx = i - ky * M1;
+      if (ky >= bh || kx >= ncol) { Xr[ky * SX + kx] = 0.0; Xi[ky * SX + kx] = 0.0; }
     }
-    Xr[i] = xr;
-    Xi[i] = xi;
+    const int hh = bh / 2;
+    const int nitem = (hh + 1) * ncol;
+    const uint32_t m_nc = pmagic((uint32_t)ncol);
+    for (int i = tid; i < nitem; i += kPBlock) {
+      const int ky = (int)__umulhi((uint32_t)i, m_nc);
+      const int kx = i - ky * ncol;
+      const int kyc = bh - ky;
+      const bool paired = (ky != 0) && (ky != hh);
+      double amp, g1, g2, h1 = 0.0, h2 = 0.0;
+      if (a.dbg & 1) { amp = 1.0; g1 = ky; g2 = kx; h1 = 1.0; h2 = 2.0; }
+      else {
+        amp = spectral_amp(P, sc, ky, kx, bh, bw);
+        normals2(seed, step, kStreamSpectrum, (uint32_t)(ky * ncol + kx), g1, g2);
+        if (paired) normals2(seed, step, kStreamSpectrum, (uint32_t)(kyc * ncol + kx), h1, h2);
+      }
+      if (kx > 0 && kx < bw / 2) {
+        Xr[ky * SX + kx] = amp * (g1 * M_SQRT1_2);
+        Xi[ky * SX + kx] = amp * (g2 * M_SQRT1_2);
+        if (paired) {
+          Xr[kyc * SX + kx] = amp * (h1 * M_SQRT1_2);
+          Xi[kyc * SX + kx] = amp * (h2 * M_SQRT1_2);
+        }
+      } else if (paired) {
+        Xr[ky * SX + kx] = amp * (0.5 * (g1 + h1));
+        Xi[ky * SX + kx] = amp * (0.5 * (g2 - h2));
+        Xr[kyc * SX + kx] = amp * (0.5 * (h1 + g1));
+        Xi[kyc * SX + kx] = amp * (0.5 * (h2 - g2));
+      } else {
+        Xr[ky * SX + kx] = amp * (0.5 * (g1 + g1));
+        Xi[ky * SX + kx] = amp * (0.5 * (g2 - g2));
+      }
+    }
   }
   __syncthreads();
 
-  // ---- stage 1: T[y, kx] = sum_ky X[ky, kx] * exp(+2 pi i ky y / bh) -----------------------------
-  for (int o = tid; o < nhalf; o += kPBlock) {
-    const int y = (int)__umulhi((uint32_t)o, m_ncol);
-    const int kx = o - y * ncol;
-    double tr = 0.0, ti = 0.0;
-    int m = 0;
-    for (int ky = 0; ky < bh; ++ky) {
-      const double c = cy[m], sn = sy[m];
-      const double xr = Xr[ky * ncol + kx], xi = Xi[ky * ncol + kx];
-      tr += xr * c - xi * sn;
-      ti += xr * sn + xi * c;
-      m += y;
-      if (m >= bh) m -= bh;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  // ---- stage 1 (MFMA): T^T[kx][y] = sum_ky X[ky][kx] (cos + i sin)(2 pi ky y / bh) ----------------
+  // results wait in registers until every wave has finished reading X, then overwrite it as T^T
+  v4f64 t1r[kMaxT1], t1i[kMaxT1];
+  const int n_mt = M1 >> 4, n_nt = N1 >> 4;
+  const int n_t1 = n_mt * n_nt;
+  {
+    const double* __restrict__ FC = a.tables + a.fy_off[bh];   // [K1][N1]
+    const double* __restrict__ FS = FC + K1 * N1;
+#pragma unroll
+    for (int j = 0; j < kMaxT1; ++j) {
+      v4f64 accr = {0.0, 0.0, 0.0, 0.0}, acci = {0.0, 0.0, 0.0, 0.0};
+      const int t = wave + j * kPWaves;
+      if (t < n_t1 && !(a.dbg & 2)) {
+        const int mt = t % n_mt, nt = t / n_mt;
+        const double* xr_p = Xr + l4 * SX + 16 * mt + l15;
+        const double* xi_p = Xi + l4 * SX + 16 * mt + l15;
+        const double* fc_p = FC + l4 * N1 + 16 * nt + l15;
+        const double* fs_p = FS + l4 * N1 + 16 * nt + l15;
+#pragma unroll 4
+        for (int k0 = 0; k0 < K1; k0 += 4) {
+          const double ar = xr_p[k0 * SX], ai = xi_p[k0 * SX];
+          const double bc = fc_p[k0 * N1], bs = fs_p[k0 * N1];
+          accr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bc, accr, 0, 0, 0);
+          accr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bs, accr, 0, 0, 0);
+          acci = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bs, acci, 0, 0, 0);
+          acci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bc, acci, 0, 0, 0);
+        }
+      }
+      t1r[j] = accr;
+      t1i[j] = acci;
     }
-    Tr[o] = tr;
-    Ti[o] = ti;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kMaxT1; ++j) {
+    const int t = wave + j * kPWaves;
+    if (t < n_t1) {
+      const int mt = t % n_mt, nt = t / n_mt;
+      const int y = 16 * nt + l15;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kx = 16 * mt + l4 + 4 * q;
+        if (kx < Kc) {
+          TT[kx * ST + y] = t1r[j][q];
+          TT[(Kc + kx) * ST + y] = t1i[j][q];
+        }
+      }
+    }
   }
   __syncthreads();
 
-  // ---- stage 2: field[y, x] = (T[y,0] + (-1)^x T[y,bw/2] + 2 Re sum_kx T[y,kx] e^{2 pi i kx x/bw}) / (bh bw)
+  // ---- stage 2 (MFMA): field[y][x] = sum_k2 T^T[k2][y] G[k2][x]; result stays in registers -------
+  v4f64 fld[kMaxT2];
+  const int n_mt2 = N1 >> 4, n_nt2 = N2 >> 4;
+  const int n_t2 = n_mt2 * n_nt2;
+  {
+    const double* __restrict__ G = a.tables + a.g_off[bw];     // [K2][N2]
+#pragma unroll
+    for (int j = 0; j < kMaxT2; ++j) {
+      fld[j] = v4f64{0.0, 0.0, 0.0, 0.0};
+      const int t = wave + j * kPWaves;
+      if (t < n_t2 && !(a.dbg & 4)) {
+        const int mt = t % n_mt2, nt = t / n_mt2;
+        const double* a_p = TT + l4 * ST + 16 * mt + l15;
+        const double* b_p = G + l4 * N2 + 16 * nt + l15;
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int k0 = 0; k0 < K2; k0 += 4)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p[k0 * ST], b_p[k0 * N2], acc, 0, 0, 0);
+        fld[j] = acc;
+      }
+    }
+  }
+
+  // ---- standardise (MCMC.py:248) on the register-resident field ---------------------------------
   const int ncell = bh * bw;
-  const uint32_t m_bw = pmagic((uint32_t)bw);
   const double inv_n = 1.0 / (double)ncell;
-  for (int o = tid; o < ncell; o += kPBlock) {
-    const int y = (int)__umulhi((uint32_t)o, m_bw);
-    const int x = o - y * bw;
-    const double* trow = Tr + y * ncol;
-    const double* tirow = Ti + y * ncol;
-    double acc = 0.0;
-    int m = x;
-    for (int kx = 1; kx < bw / 2; ++kx) {
-      acc += trow[kx] * cx[m] - tirow[kx] * sx[m];
-      m += x;
-      if (m >= bw) m -= bw;
-    }
-    const double edge = trow[0] + ((x & 1) ? -trow[bw / 2] : trow[bw / 2]);
-    fieldv[o] = (edge + 2.0 * acc) * inv_n;
-  }
-  __syncthreads();
-
-  // ---- standardise (MCMC.py:248), scale, nugget (MCMC.py:251), edge mask (MCMC.py:778) ---------
   double part = 0.0;
-  for (int o = tid; o < ncell; o += kPBlock) part += fieldv[o];
-  const double mean = block_sum(part, red, tid) / (double)ncell;
-  part = 0.0;
-  for (int o = tid; o < ncell; o += kPBlock) { const double d = fieldv[o] - mean; part += d * d; }
-  const double sd = sqrt(block_sum(part, red, tid) / (double)ncell);
-  const double denom = sd + 1e-12;
-  const double* mask = a.B.masks + a.B.mask_off[si];
-  double* out = a.fields + rec * a.field_stride;
-  const double sq_nug = sqrt(nug);
-  const bool with_nugget = (P.nugget_max > 0.0);
-  for (int o = tid; o < ncell; o += kPBlock) {
-    double v = ((fieldv[o] - mean) / denom) * scale;
-    if (with_nugget) {
-      double n1, n2;
-      normals2(seed, step, kStreamNugget, (uint32_t)(o >> 1), n1, n2);
-      v = v + ((o & 1) ? n2 : n1) * sq_nug;
+#pragma unroll
+  for (int j = 0; j < kMaxT2; ++j) {
+    const int t = wave + j * kPWaves;
+    const int mt = t % n_mt2, nt = t / n_mt2;
+    const int x = 16 * nt + l15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int y = 16 * mt + l4 + 4 * q;
+      const bool ok = (t < n_t2) && (y < bh) && (x < bw);
+      fld[j][q] = ok ? fld[j][q] * inv_n : 0.0;
+      part += fld[j][q];
     }
-    out[o] = v * mask[o];
+  }
+  const double mean = block_sum(part, red, tid) * inv_n;
+  part = 0.0;
+#pragma unroll
+  for (int j = 0; j < kMaxT2; ++j) {
+    const int t = wave + j * kPWaves;
+    const int mt = t % n_mt2, nt = t / n_mt2;
+    const int x = 16 * nt + l15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int y = 16 * mt + l4 + 4 * q;
+      if ((t < n_t2) && (y < bh) && (x < bw)) { const double d = fld[j][q] - mean; part += d * d; }
+    }
+  }
+  const double sd = sqrt(block_sum(part, red, tid) * inv_n);
+  const double gain = sc.scale / (sd + 1e-12);
+
+  // ---- scale, nugget (MCMC.py:251), edge mask (MCMC.py:778), store ------------------------------
+  const double* __restrict__ mask = a.B.masks + a.B.mask_off[si];
+  double* __restrict__ out = a.fields + rec * a.field_stride;
+  const double sq_nug = sqrt(sc.nug);
+  const bool with_nugget = (P.nugget_max > 0.0);
+#pragma unroll
+  for (int j = 0; j < kMaxT2; ++j) {
+    const int t = wave + j * kPWaves;
+    const int mt = t % n_mt2, nt = t / n_mt2;
+    const int x = 16 * nt + l15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int y = 16 * mt + l4 + 4 * q;
+      if ((t < n_t2) && (y < bh) && (x < bw)) {
+        const int o = y * bw + x;
+        double v = (fld[j][q] - mean) * gain;
+        if (with_nugget) {
+          double n1, n2;
+          normals2(seed, step, kStreamNugget, (uint32_t)(o >> 1), n1, n2);
+          v = v + ((o & 1) ? n2 : n1) * sq_nug;
+        }
+        out[o] = v * mask[o];
+      }
+    }
   }
 }
 
-static size_t propose_lds_doubles(const BlockTable& B, int* cap_half_out) {
-  const int cap_half = B.max_bh * (B.max_bw / 2 + 1);
-  *cap_half_out = cap_half;
-  return (size_t)4 * cap_half + 2 * (size_t)B.max_bh + 2 * (size_t)B.max_bw + kPWaves;
-}
-
-hipError_t launch_propose(const ProposeArgs& a, hipStream_t st) {
-  int cap_half = 0;
-  const size_t lds = propose_lds_doubles(a.B, &cap_half) * sizeof(double);
+hipError_t launch_propose(const ProposeArgs& a_in, hipStream_t st) {
+  ProposeArgs a = a_in;
+  { static int dbg = -1; if (dbg < 0) { const char* v = getenv("GSM_PROPOSE_DBG"); dbg = v ? atoi(v) : 0; } a.dbg = dbg; }
+  const size_t lds = ((size_t)a.lds_main + kPWaves) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)propose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -237,13 +356,19 @@ hipError_t launch_propose(const ProposeArgs& a, hipStream_t st) {
     attr_set = true;
   }
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(propose_kernel, dim3(a.n_steps, a.n_chains), dim3(kPBlock), lds, st, a, cap_half);
+  const int64_t nrec = (int64_t)a.n_chains * a.n_steps;
+  hipLaunchKernelGGL(propose_scalars_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(propose_kernel, dim3(a.n_steps, a.n_chains), dim3(kPBlock), lds, st, a);
   return hipGetLastError();
 }
 
-// host-visible self test of the Philox implementation (used by the C ABI below)
+int propose_max_tiles1_per_wave() { return kMaxT1; }
+int propose_max_tiles_per_wave() { return kMaxT2; }
+int propose_waves() { return kPWaves; }
+
 }  // namespace gsm
 
+// host-visible self test of the Philox implementation (declared in include/gsm.h)
 extern "C" int gsm_philox_selftest(const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4) {
   gsm::u32x4 c{ctr4[0], ctr4[1], ctr4[2], ctr4[3]};
   const gsm::u32x4 r = gsm::philox4x32_10(c, key2[0], key2[1]);

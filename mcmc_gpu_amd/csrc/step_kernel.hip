@@ -1,5 +1,5 @@
-// Metropolis step kernels for gfx950 (MI355X): one 256-thread workgroup per chain, the proposal
-// window (+1-cell halo) of the chain's bed staged in LDS, all steps of a launch looped inside the kernel.
+// Metropolis step kernels for gfx950 (MI355X): one workgroup per chain, the CANDIDATE bed of the proposal
+// window (+1-cell halo) staged in LDS, all steps of a launch looped inside the kernel.
 //
 // Replaces the loop body of chain_crf.run (reference gstatsMCMC/MCMC.py:1263-1360):
 //   window/clipping         MCMC.py:1266-1276
@@ -9,34 +9,45 @@
 //   thickness guard         MCMC.py:1321-1329
 //   accept / bookkeeping    MCMC.py:1331-1360
 //
-// What is NOT done the reference's way, and why the result is the same:
-//   * No residual array is carried.  The edge taper is exactly 0 on the block border (MCMC.py:583-623 with
-//     the driver's logistic parameters), so a proposal changes the residual only inside its window and the
-//     carried array always equals a recompute from the current bed.  The kernel recomputes the window's OLD
-//     residuals from the staged bed, applies the perturbation in LDS and recomputes the NEW ones:
-//         sum_next = sum_prev - sum_window(old r^2) + sum_window(new r^2)
-//     with sum_prev kept as a compensated (hi, lo) pair, instead of the O(H*W) gather + nansum per step.
-//     Arithmetic per residual is the reference's, operation for operation (no FMA contraction: this file is
-//     built with -ffp-contract=off), so only the summation order differs (|rel diff| ~1e-15, test bound 1e-10).
-//   * Full-grid copies (MCMC.py:1284, :1288, :1308, :1338) do not exist; accepted windows are written back.
+// What is carried between steps (per chain, in HBM): the bed, the "energy" e = r^2 where the cell enters the loss
+// (mc_mask == 1 and r is not NaN -- nansum semantics, MCMC.py:1041) else 0, the uint32 resampled counts, and the
+// compensated pair (hi, lo) with hi + lo = sum(e).  The reference carries the residual array r itself
+// (MCMC.py:1308-1315, :1340) and re-reduces the whole grid every step; because the edge taper is exactly 0 on the
+// block border (MCMC.py:583-623 with the driver's logistic parameters) a proposal changes r only inside its window,
+// so   sum_next = sum_prev - sum_window(e_old) + sum_window(e_new)   is the same quantity.  Arithmetic per residual
+// is the reference's, operation for operation (this file is built with -ffp-contract=off; the only fused op is the
+// explicit fma pair of exact_div, which returns the correctly rounded quotient), so only the summation order of the
+// loss differs (|rel diff| ~1e-15; test bound 1e-10) and accept decisions are identical.
 //
-// HBM traffic per chain-step: read (bh+2)(bw+2) bed cells; on accept write bh*bw bed cells and
-// read-modify-write bh*bw uint32 resampled counts.  Static fields are shared by all chains (L2-resident).
+// Per step:  A  stage bed window+halo in LDS with the perturbation already applied (f * weight where update_mask),
+//               thickness guard, and sum the carried e of the window          -- 1 barrier
+//            D  5-point stencil on the LDS tile -> e_new kept in registers, summed
+//            R  workgroup reduction, every thread evaluates the same accept test -- 1 barrier
+//            E  on accept: write bed window, e window, bump resampled           -- 1 barrier
+// HBM bytes per chain-step: read (bh+2)(bw+2) bed + bh*bw e + bh*bw f; on accept write bh*bw bed + bh*bw e and
+// read-modify-write bh*bw uint32.  Static fields are shared by all chains and stay in L2 / Infinity Cache.
 
 #include "gsm_internal.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace gsm {
-
-constexpr int kBlock = 256;
-constexpr int kWaves = kBlock / 64;
 
 __device__ __forceinline__ uint32_t magic_for(uint32_t d) {
   // q = __umulhi(n, M) == n / d for n*d < 2^32 (here n < 2^16, d < 2^8)
   return (uint32_t)(0xFFFFFFFFu / d) + 1u;
 }
 
-// Residual of cell (r, c) of the full grid.  `bed_at(rr, cc)` returns the bed value of a grid cell.
+// Correctly rounded x / d from y = RN(1/d): q0 = RN(x*y), r = x - q0*d (exact in an fma), q = RN(q0 + r*y)
+// (Markstein 1990).  Enabled by the host only when d's significand is not all ones and d is far from the
+// exponent limits; tests/test_exact_div.py checks it against exact rational arithmetic.
+__device__ __forceinline__ double exact_div(double x, double d, double y) {
+  const double q0 = x * y;
+  const double r = __fma_rn(-q0, d, x);
+  return __fma_rn(r, y, q0);
+}
+
+// Residual of cell (r, c) of the full grid from plain arrays (init / residual kernels).
 // np.gradient semantics: interior (f[i+1]-f[i-1])/(2.0*h); first/last (f[1]-f[0])/h, (f[-1]-f[-2])/h.
 template <class BedAt>
 __device__ __forceinline__ double cell_residual(const StaticFields& S, int r, int c, BedAt bed_at) {
@@ -70,12 +81,14 @@ __device__ __forceinline__ void two_sum(double a, double b, double& s, double& e
 }
 
 // ---------------------------------------------------------------------------------------------------
-// step kernel
+// step kernel.  NT threads per workgroup, KMAX = ceil(max window cells / NT) window cells per thread.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
+template <int NT, int KMAX, bool FAST_DIV, int MINW>
+__global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
+  constexpr int NW = NT / 64;
   extern __shared__ double lds[];
   double* tile = lds;
-  double* red = lds + a.tile_cap;  // [kWaves][3]
+  double* red = lds + a.tile_cap;  // [NW][3]
 
   const StaticFields& S = a.S;
   const int tid = threadIdx.x;
@@ -83,8 +96,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
   const int chain = blockIdx.x;
   const int H = S.H, W = S.W;
   const size_t plane = (size_t)H * W;
-  double* bed = a.beds + (size_t)chain * plane;
-  uint32_t* resamp = a.resampled + (size_t)chain * plane;
+  double* __restrict__ bed = a.beds + (size_t)chain * plane;
+  double* __restrict__ energy = a.energy + (size_t)chain * plane;
+  uint32_t* __restrict__ resamp = a.resampled + (size_t)chain * plane;
+  const double2* __restrict__ svx = S.svx;
+  const double2* __restrict__ svy = S.svy;
+  const double2* __restrict__ dsp = S.ds;
 
   double s_hi = a.loss_sum[2 * chain], s_lo = a.loss_sum[2 * chain + 1];
   double loss_prev = (s_hi + s_lo) / S.two_sigma2;
@@ -105,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
     }
     const int bh = a.B.bh[si], bw = a.B.bw[si];
     const double uu = a.u[rin];
-    const double* fld = a.fields + rin * a.field_stride;
+    const double* __restrict__ fld = a.fields + rin * a.field_stride;
 
     // window, clipped to the grid, and the matching sub-block of f (MCMC.py:1266-1276)
     const int r0 = max(0, row - bh / 2), r1 = min(H, row + bh / 2);
@@ -117,60 +134,72 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
     const int hc0 = max(0, c0 - 1), hc1 = min(W, c1 + 1);
     const int th = hr1 - hr0, tw = hc1 - hc0;
     const int ncell = th * tw, nwin = wh * ww;
-    const uint32_t m_tw = magic_for((uint32_t)tw), m_ww = magic_for((uint32_t)max(ww, 1));
+    const uint32_t m_tw = magic_for((uint32_t)tw), m_ww = magic_for((uint32_t)ww);
+    const int dr = r0 - hr0, dc = c0 - hc0;  // window origin inside the tile (0 or 1)
 
-    // A: stage the bed window + halo
-    for (int i = tid; i < ncell; i += kBlock) {
+    // ---- A: candidate bed -> LDS, guard, sum of the carried energy of the window ------------------
+    double acc_old = 0.0;
+    int guard = 0;
+#pragma unroll 2
+    for (int i = tid; i < ncell; i += NT) {
       const int lr = (int)__umulhi((uint32_t)i, m_tw);
       const int lc = i - lr * tw;
-      tile[i] = bed[(size_t)(hr0 + lr) * W + hc0 + lc];
-    }
-    __syncthreads();
-
-    auto tile_at = [&](int rr, int cc) { return tile[(rr - hr0) * tw + (cc - hc0)]; };
-
-    // B: sum of squared residuals of the window under the current bed
-    double acc_old = 0.0;
-    for (int i = tid; i < nwin; i += kBlock) {
-      const int wr = (int)__umulhi((uint32_t)i, m_ww);
-      const int wc = i - wr * ww;
-      const int r = r0 + wr, c = c0 + wc;
-      if (S.mc[r * W + c] == 1) {
-        const double v = cell_residual(S, r, c, tile_at);
-        if (!isnan(v)) acc_old += v * v;
+      const int g = (hr0 + lr) * W + hc0 + lc;
+      double v = bed[g];
+      const int wr = lr - dr, wc = lc - dc;
+      if ((unsigned)wr < (unsigned)wh && (unsigned)wc < (unsigned)ww) {
+        acc_old += energy[g];
+        if (S.upd[g]) {
+          const double f = fld[(mr0 + wr) * bw + mc0 + wc];
+          const double pert = S.weight ? f * S.weight[g] : f;
+          v = v + pert;
+          if (svx[g].x - v <= 0.0) guard = 1;
+        }
       }
+      tile[i] = v;
     }
     __syncthreads();
 
-    // C: candidate bed in place (perturbation, update mask) and thickness guard
-    int guard = 0;
-    for (int i = tid; i < nwin; i += kBlock) {
-      const int wr = (int)__umulhi((uint32_t)i, m_ww);
-      const int wc = i - wr * ww;
-      const int r = r0 + wr, c = c0 + wc;
-      const int g = r * W + c;
-      if (S.upd[g]) {
-        const double f = fld[(mr0 + wr) * bw + mc0 + wc];
-        const double pert = S.weight ? f * S.weight[g] : f;
-        const int t = (r - hr0) * tw + (c - hc0);
-        const double bn = tile[t] + pert;
-        tile[t] = bn;
-        if (S.surf[g] - bn <= 0.0) guard = 1;
-      }
-    }
-    __syncthreads();
-
-    // D: sum of squared residuals of the window under the candidate bed
+    // ---- D: residual stencil on the candidate tile ---------------------------------------------------
+    double e_new[KMAX];
     double acc_new = 0.0;
-    for (int i = tid; i < nwin; i += kBlock) {
-      const int wr = (int)__umulhi((uint32_t)i, m_ww);
-      const int wc = i - wr * ww;
-      const int r = r0 + wr, c = c0 + wc;
-      if (S.mc[r * W + c] == 1) {
-        const double v = cell_residual(S, r, c, tile_at);
-        if (!isnan(v)) acc_new += v * v;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int i = tid + k * NT;
+      double e = 0.0;
+      if (i < nwin) {
+        const int wr = (int)__umulhi((uint32_t)i, m_ww);
+        const int wc = i - wr * ww;
+        const int r = r0 + wr, c = c0 + wc;
+        const int g = r * W + c;
+        if (S.mc[g] == 1) {
+          const int cl = (c == 0) ? 0 : c - 1, cr = (c == W - 1) ? W - 1 : c + 1;
+          const int ru = (r == 0) ? 0 : r - 1, rd = (r == H - 1) ? H - 1 : r + 1;
+          const double2 xr = svx[r * W + cr], xl = svx[r * W + cl];
+          const double2 yd = svy[rd * W + c], yu = svy[ru * W + c];
+          const double2 dd = dsp[g];
+          const int trow = (r - hr0) * tw - hc0;
+          const double qxr = xr.y * (xr.x - tile[trow + cr]);
+          const double qxl = xl.y * (xl.x - tile[trow + cl]);
+          const double qyd = yd.y * (yd.x - tile[(rd - hr0) * tw + (c - hc0)]);
+          const double qyu = yu.y * (yu.x - tile[(ru - hr0) * tw + (c - hc0)]);
+          double dx, dy;
+          if (FAST_DIV) {
+            dx = (cr - cl == 2) ? exact_div(qxr - qxl, S.two_res, S.rcp_two_res) : exact_div(qxr - qxl, S.res, S.rcp_res);
+            dy = (rd - ru == 2) ? exact_div(qyd - qyu, S.two_res, S.rcp_two_res) : exact_div(qyd - qyu, S.res, S.rcp_res);
+          } else {
+            dx = (qxr - qxl) / ((cr - cl == 2) ? S.two_res : S.res);
+            dy = (qyd - qyu) / ((rd - ru == 2) ? S.two_res : S.res);
+          }
+          const double v = ((dx + dy) + dd.x) - dd.y;
+          if (!isnan(v)) e = v * v;
+        }
       }
+      e_new[k] = e;
+      acc_new += e;
     }
+
+    // ---- R: reduce, decide (every thread evaluates the same numbers in the same order) ----------------
     acc_old = wave_sum(acc_old);
     acc_new = wave_sum(acc_new);
     const int any_guard = __any(guard);
@@ -180,11 +209,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
       red[wave * 3 + 2] = any_guard ? 1.0 : 0.0;
     }
     __syncthreads();
-
-    // every thread evaluates the same decision from the same partials (fixed order => deterministic)
     double so = 0.0, sn = 0.0, gd = 0.0;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) { so += red[w * 3]; sn += red[w * 3 + 1]; gd += red[w * 3 + 2]; }
+    for (int w = 0; w < NW; ++w) { so += red[w * 3]; sn += red[w * 3 + 1]; gd += red[w * 3 + 2]; }
     double c_hi, c_err;
     two_sum(s_hi, sn - so, c_hi, c_err);
     const double c_lo = s_lo + c_err;
@@ -193,19 +220,23 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
     const double p_acc = (loss_prev > loss_next) ? 1.0 : fmin(1.0, exp(loss_prev - loss_next));
     const bool acc = (uu <= p_acc);
 
-    // E: commit
+    // ---- E: commit -------------------------------------------------------------------------------------
     if (acc) {
-      for (int i = tid; i < nwin; i += kBlock) {
-        const int wr = (int)__umulhi((uint32_t)i, m_ww);
-        const int wc = i - wr * ww;
-        const int r = r0 + wr, c = c0 + wc;
-        const size_t g = (size_t)r * W + c;
-        if (S.upd[g]) {
-          bed[g] = tile[(r - hr0) * tw + (c - hc0)];
-          if (S.upd[g] == 1) resamp[g] += 1u;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        const int i = tid + k * NT;
+        if (i < nwin) {
+          const int wr = (int)__umulhi((uint32_t)i, m_ww);
+          const int wc = i - wr * ww;
+          const int r = r0 + wr, c = c0 + wc;
+          const size_t g = (size_t)r * W + c;
+          energy[g] = e_new[k];
+          if (S.upd[g]) {
+            bed[g] = tile[(r - hr0) * tw + (c - hc0)];
+            resamp[g] += 1u;
+          }
         }
       }
-      // renormalise the pair
       two_sum(c_hi, c_lo, s_hi, s_lo);
       loss_prev = loss_next;
     }
@@ -214,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
       a.accept[rout] = acc ? 1 : 0;
       if (a.blocks) { a.blocks[4 * rout] = row; a.blocks[4 * rout + 1] = col; a.blocks[4 * rout + 2] = bh; a.blocks[4 * rout + 3] = bw; }
     }
-    __syncthreads();  // tile/red reuse + this step's bed stores visible to the next step's loads
+    __syncthreads();  // tile/red reuse + this step's stores visible to the next step's loads
   }
   if (tid == 0) {
     a.loss_sum[2 * chain] = s_hi;
@@ -222,43 +253,72 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
   }
 }
 
-size_t step_lds_bytes(int tile_cap) { return ((size_t)tile_cap + 3 * kWaves) * sizeof(double); }
+size_t step_lds_bytes(int tile_cap) { return ((size_t)tile_cap + 3 * 16) * sizeof(double); }
 
-hipError_t launch_step(const StepArgs& a, hipStream_t st) {
+template <int NT, int KMAX, int MINW>
+static hipError_t launch_step_t(const StepArgs& a, hipStream_t st) {
   const size_t lds = step_lds_bytes(a.tile_cap);
+  auto kfast = step_kernel<NT, KMAX, true, MINW>;
+  auto kslow = step_kernel<NT, KMAX, false, MINW>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)kfast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kslow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(step_kernel, dim3(a.n_chains), dim3(kBlock), lds, st, a);
+  if (a.S.fast_div) hipLaunchKernelGGL(kfast, dim3(a.n_chains), dim3(NT), lds, st, a);
+  else hipLaunchKernelGGL(kslow, dim3(a.n_chains), dim3(NT), lds, st, a);
   return hipGetLastError();
 }
 
+hipError_t launch_step(const StepArgs& a, hipStream_t st) {
+  // window cells per thread: the largest block of the table decides the instantiation
+  const int max_win = a.B.max_bh * a.B.max_bw;
+  static int variant = -1;
+  if (variant < 0) { const char* v = getenv("GSM_STEP_VARIANT"); variant = v ? atoi(v) : 1; }
+  if (max_win <= 1024 * 7) {
+    switch (variant) {
+      case 0: return launch_step_t<1024, 7, 4>(a, st);
+      case 2: return launch_step_t<512, 13, 4>(a, st);
+      case 3: return launch_step_t<512, 13, 6>(a, st);    // <=80 VGPRs: 3 workgroups per CU
+      case 4: return launch_step_t<256, 25, 2>(a, st);
+      default: return launch_step_t<1024, 7, 8>(a, st);   // <=64 VGPRs: 2 workgroups per CU (fastest measured)
+    }
+  }
+  if (max_win <= 1024 * 12) return launch_step_t<1024, 12, 4>(a, st);
+  if (max_win <= 1024 * 20) return launch_step_t<1024, 20, 4>(a, st);
+  return hipErrorInvalidValue;  // gsm_set_blocks refuses such tables (LDS tile limit is reached first)
+}
+
 // ---------------------------------------------------------------------------------------------------
-// full-grid residual + loss of the current beds (MCMC.py:1189-1195)
+// full-grid residual, energy and loss of the current beds (MCMC.py:1189-1195)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void init_loss_kernel(const StaticFields S, const double* beds,
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+__global__ __launch_bounds__(kBlock) void init_loss_kernel(const StaticFields S, const double* beds, double* energy,
                                                            double* loss_sum, double* loss0) {
   __shared__ double red[kWaves * 2];
   const int chain = blockIdx.x, tid = threadIdx.x;
   const size_t plane = (size_t)S.H * S.W;
   const double* bed = beds + (size_t)chain * plane;
+  double* en = energy ? energy + (size_t)chain * plane : nullptr;
   auto bed_at = [&](int rr, int cc) { return bed[(size_t)rr * S.W + cc]; };
   // per-thread compensated partial
   double hi = 0.0, lo = 0.0;
   for (int g = tid; g < (int)plane; g += kBlock) {
+    double e = 0.0;
     if (S.mc[g] == 1) {
       const int r = g / S.W, c = g - r * S.W;
       const double v = cell_residual(S, r, c, bed_at);
-      if (!isnan(v)) {
-        double s, e;
-        two_sum(hi, v * v, s, e);
-        hi = s;
-        lo += e;
-      }
+      if (!isnan(v)) e = v * v;
     }
+    if (en) en[g] = e;
+    double s, err;
+    two_sum(hi, e, s, err);
+    hi = s;
+    lo += err;
   }
   // wave tree on (hi, lo) with two_sum at each level
 #pragma unroll
@@ -287,9 +347,25 @@ __global__ __launch_bounds__(kBlock) void init_loss_kernel(const StaticFields S,
   }
 }
 
-hipError_t launch_init_loss(const StaticFields& S, int n_chains, const double* beds, double* loss_sum,
-                            double* loss0, hipStream_t st) {
-  hipLaunchKernelGGL(init_loss_kernel, dim3(n_chains), dim3(kBlock), 0, st, S, beds, loss_sum, loss0);
+hipError_t launch_init_loss(const StaticFields& S, int n_chains, const double* beds, double* energy,
+                            double* loss_sum, double* loss0, hipStream_t st) {
+  hipLaunchKernelGGL(init_loss_kernel, dim3(n_chains), dim3(kBlock), 0, st, S, beds, energy, loss_sum, loss0);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(kBlock) void pack_static_kernel(const StaticFields S, double2* svx, double2* svy, double2* ds) {
+  const int n = S.H * S.W;
+  for (int g = blockIdx.x * kBlock + threadIdx.x; g < n; g += gridDim.x * kBlock) {
+    svx[g] = make_double2(S.surf[g], S.velx[g]);
+    svy[g] = make_double2(S.surf[g], S.vely[g]);
+    ds[g] = make_double2(S.dhdt[g], S.smb[g]);
+  }
+}
+
+hipError_t launch_pack_static(const StaticFields& S, double2* svx, double2* svy, double2* ds, hipStream_t st) {
+  int grid = (S.H * S.W + kBlock - 1) / kBlock;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(pack_static_kernel, dim3(grid), dim3(kBlock), 0, st, S, svx, svy, ds);
   return hipGetLastError();
 }
 

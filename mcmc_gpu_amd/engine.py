@@ -41,7 +41,7 @@ class GsmEngine:
         if rc != 0:
             raise GsmError(rc, self.lib.gsm_last_error(None).decode())
         self.h = h
-        self.beds = self.resampled = self.loss_sum = None
+        self.beds = self.energy = self.resampled = self.loss_sum = None
         self.field_stride = 0
         self.n_sizes = 0
         self._keep = []
@@ -137,9 +137,11 @@ class GsmEngine:
         else:
             self.resampled = torch.as_tensor(resampled).to(device=self.dev, dtype=torch.int32).contiguous()
         self.loss_sum = torch.zeros((self.n_chains, 2), dtype=torch.float64, device=self.dev)
+        self.energy = torch.empty((self.n_chains, self.H, self.W), dtype=torch.float64, device=self.dev)
         loss0 = torch.zeros(self.n_chains, dtype=torch.float64, device=self.dev)
         with torch.cuda.device(self.dev):
-            self._check(self.lib.gsm_init_loss(self.h, _ptr(self.beds), _ptr(self.loss_sum), _ptr(loss0), self._stream()))
+            self._check(self.lib.gsm_init_loss(self.h, _ptr(self.beds), _ptr(self.energy), _ptr(self.loss_sum), _ptr(loss0),
+                                               self._stream()))
         return loss0.cpu().numpy()
 
     def residual(self, beds):
@@ -190,7 +192,7 @@ class GsmEngine:
         loss = torch.empty((self.n_chains, n_steps), dtype=torch.float64, device=self.dev)
         acc = torch.empty((self.n_chains, n_steps), dtype=torch.uint8, device=self.dev)
         with torch.cuda.device(self.dev):
-            self._check(self.lib.gsm_run_replay(self.h, n_steps, _ptr(self.beds), _ptr(self.resampled), _ptr(self.loss_sum),
+            self._check(self.lib.gsm_run_replay(self.h, n_steps, _ptr(self.beds), _ptr(self.energy), _ptr(self.resampled), _ptr(self.loss_sum),
                                                 _ptr(d_si), _ptr(d_c), _ptr(d_u), _ptr(f), self.field_stride,
                                                 _ptr(loss), _ptr(acc), self._stream()))
         return loss.cpu().numpy(), acc.cpu().numpy()
@@ -258,7 +260,7 @@ class GsmEngine:
         p = rf if isinstance(rf, RfParams) else self.rf_struct(rf)
         with torch.cuda.device(self.dev):
             self._check(self.lib.gsm_run_philox(self.h, int(n_steps), int(step0), int(batch), _ptr(d_seeds), C.byref(p),
-                                                _ptr(self.beds), _ptr(self.resampled), _ptr(self.loss_sum),
+                                                _ptr(self.beds), _ptr(self.energy), _ptr(self.resampled), _ptr(self.loss_sum),
                                                 _ptr(loss), _ptr(acc), _ptr(blocks), self._stream()))
         if to_host:
             return loss.cpu().numpy(), acc.cpu().numpy(), blocks.cpu().numpy()
