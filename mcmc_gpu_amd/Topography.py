@@ -16,8 +16,8 @@ def _residual_device(bed, surf, velx, vely, dhdt, smb, resolution):
     batched = b.ndim == 3
     b3 = b if batched else b[None]
     H, W = b3.shape[1:]
-    to_np = lambda a: np.broadcast_to(np.asarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a,
-                                                 dtype=np.float64), (H, W))
+    to_np = lambda a: np.array(np.broadcast_to(np.asarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a,
+                                                          dtype=np.float64), (H, W)))
     eng = GsmEngine(H, W, b3.shape[0])
     try:
         ones = np.ones((H, W), dtype=np.uint8)

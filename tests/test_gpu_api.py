@@ -1,0 +1,163 @@
+"""-m gpu: the reference-compatible Python surface (mcmc_gpu_amd.MCMC_gpu / driver / Topography) on the device,
+against golden fixtures generated from the reference itself and against the oracle."""
+import json
+from copy import deepcopy
+
+import numpy as np
+import pytest
+
+import mcmc_oracle as orc
+from mcmc_gpu_amd import MCMC_gpu, Topography, driver, synthetic
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+def _rehydrate(ch, rf, seed, bed):
+    cp = deepcopy(ch.__dict__); cp["rng_seed"] = seed; cp["initial_bed"] = bed
+    rp = deepcopy(rf.__dict__); rp["rng_seed"] = seed
+    return MCMC_gpu.init_lsc_chain_by_instance(cp), MCMC_gpu.initiate_RF_by_instance(rp), cp, rp
+
+
+def test_run_replay_equals_reference_chain(golden_dir):
+    """chain_crf_gpu.run on seeds of fixture F1 (reference chain_crf.run, 300 iterations)."""
+    g = np.load(golden_dir / "f1_chain64_standard.npz")
+    prob, ch, rf = synthetic.template(64)
+    c, r, _, _ = _rehydrate(ch, rf, 7, prob["bed"].copy())
+    c.replay_chunk = 64
+    out = c.run(300, r, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None)
+    bed, loss_mc, loss_data, loss, steps, resampled, blocks = out
+    assert np.array_equal(bed, g["bed"])
+    assert np.array_equal(steps, g["steps"])
+    assert np.array_equal(blocks, g["blocks"], equal_nan=True)
+    assert np.array_equal(resampled, g["resampled"])
+    np.testing.assert_allclose(loss, g["loss"], rtol=RTOL)
+    assert np.array_equal(loss_mc, loss) and not loss_data.any()
+    assert all(isinstance(a, np.ndarray) and a.dtype == np.float64 for a in out)
+    # generators advanced exactly as in the reference
+    o = orc.run_standard_chain(64, 300, record=False)
+    assert np.array_equal(o[0], bed)
+
+
+def test_run_keeps_every_bed_and_sample_points():
+    prob, ch, rf = synthetic.template(64)
+    c, r, _, _ = _rehydrate(ch, rf, 9, prob["bed"].copy())
+    loc = np.array([[prob["xx"][20, 30], prob["yy"][20, 30]], [prob["xx"][40, 12], prob["yy"][40, 12]]])
+    c.set_sample_points_locations(loc)
+    out = c.run(25, r, only_save_last_bed=False, info_per_iter=10 ** 9, plot=False, progress_bar=None)
+    assert len(out) == 8
+    bed_cache, *_rest, sample_values = out
+    assert bed_cache.shape == (25, 64, 64) and sample_values.shape == (2, 25)
+    assert np.array_equal(bed_cache[0], prob["bed"])
+    assert np.array_equal(sample_values[0], bed_cache[:, 20, 30]) and np.array_equal(sample_values[1], bed_cache[:, 40, 12])
+    # same chain through the oracle with every bed kept
+    p2, cfg, pairs, masks, rfp = orc.standard_setup(64)
+    o = orc.run_chain(cfg, prob["bed"].copy(), 25, orc.OracleRandField(rfp, 9, pairs, masks, 500.0),
+                      np.random.default_rng(9), only_save_last_bed=False)
+    assert np.array_equal(bed_cache, o[0])
+    assert np.array_equal(out[4], o[4])
+
+
+def test_wrapper_two_segments_files_equal_reference(golden_dir, tmp_path):
+    """lsc_run_wrapper twice (resume from files) == the reference wrapper's files and contents (fixture F7)."""
+    g = np.load(golden_dir / "f7_wrapper_two_segments.npz")
+    seed = int(g["seed"])
+    prob, ch, rf = synthetic.template(64)
+    outdir = tmp_path / "LargeScaleChain"
+    (outdir / str(seed)[:6]).mkdir(parents=True)
+    for _ in range(2):
+        cp = deepcopy(ch.__dict__); cp["rng_seed"] = seed; cp["initial_bed"] = prob["bed"].copy()
+        rp = deepcopy(rf.__dict__); rp["rng_seed"] = seed
+        runp = dict(n_iter=1000, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=False,
+                    chain_id=0, tqdm_position=1, seed=seed, output_path=str(outdir))
+        driver.lsc_run_wrapper(cp, rp, runp)
+    folder = outdir / str(seed)[:6]
+    files = sorted(p.name for p in folder.iterdir())
+    assert [f for f in files if f != "RNGState_philox.txt"] == sorted(g["files"].tolist())
+    assert np.array_equal(np.load(folder / "bed_2k.npy"), g["bed_2k"])
+    with np.load(folder / "results_2k.npz") as r:
+        assert sorted(r.files) == ["blocks_used", "loss", "loss_data", "loss_mc", "resampled_times", "steps"]
+        assert np.array_equal(r["steps"], g["res_steps"])
+        assert np.array_equal(r["blocks_used"], g["res_blocks_used"], equal_nan=True)
+        assert np.array_equal(r["resampled_times"], g["res_resampled_times"])
+        np.testing.assert_allclose(r["loss"], g["res_loss"], rtol=RTOL)
+        np.testing.assert_allclose(r["loss_mc"], g["res_loss_mc"], rtol=RTOL)
+    assert int(np.loadtxt(folder / "current_iter.txt")) == 2000
+    assert json.load(open(folder / "RNGState_chain.txt")) == json.loads(str(g["rng_state_chain"]))
+    assert json.load(open(folder / "RNGState_RandField.txt")) == json.loads(str(g["rng_state_randfield"]))
+
+
+def test_philox_accept_rate_parity_with_cpu_path():
+    """Philox-mode chains vs the oracle's (reference-identical) CPU chains on the same problem: pooled accept
+    rate within 0.02 and mean loss trajectory within MC error.  Different random numbers, same sampler."""
+    prob, ch, rf = synthetic.template(64)
+    n_chains, n_iter = 48, 401
+    beds = synthetic.initial_beds(prob, n_chains)
+    res = MCMC_gpu.run_many(ch, rf, beds, [1000 + i for i in range(n_chains)], n_iter, batch=16)
+    acc_gpu = np.mean([r[4][1:].mean() for r in res])
+    loss_gpu = np.mean([r[3][-1] for r in res])
+    p2, cfg, pairs, masks, rfp = orc.standard_setup(64)
+    acc_cpu, loss_cpu = [], []
+    for c in range(12):
+        o = orc.run_chain(cfg, orc.chain_initial_bed(p2, c), n_iter, orc.OracleRandField(rfp, 50 + c, pairs, masks, 500.0),
+                          np.random.default_rng(50 + c))
+        acc_cpu.append(o[4][1:].mean()); loss_cpu.append(o[3][-1])
+    assert abs(acc_gpu - np.mean(acc_cpu)) < 0.02, (acc_gpu, np.mean(acc_cpu))
+    # chain 0 starts from the unperturbed bed (lower loss): compare the perturbed-start chains
+    lg = np.mean([r[3][-1] for r in res[1:13]]); lc = np.mean(loss_cpu[1:])
+    assert abs(lg - lc) < 0.05 * lc, (lg, lc)
+    # run_many result layout == chain.run(only_save_last_bed=True)
+    bed, loss_mc, loss_data, loss, steps, resampled, blocks = res[3]
+    assert bed.shape == (64, 64) and loss.shape == (n_iter,) and blocks.shape == (n_iter, 4)
+    assert steps[0] == 0 and np.isnan(blocks[0]).all() and not np.isnan(blocks[1:]).any()
+    assert resampled.sum() > 0 and set(np.unique(steps)) <= {0.0, 1.0}
+
+
+def test_philox_run_is_reproducible_and_segmentable():
+    prob, ch, rf = synthetic.template(64)
+    beds = synthetic.initial_beds(prob, 3)
+    a = MCMC_gpu.run_many(ch, rf, beds, [5, 6, 7], 101, batch=8)
+    b = MCMC_gpu.run_many(ch, rf, beds, [5, 6, 7], 101, batch=32)
+    for ra, rb in zip(a, b):
+        assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(ra, rb))
+    # two segments of 51 iterations (50 proposals each) == one of 101
+    s1 = MCMC_gpu.run_many(ch, rf, beds, [5, 6, 7], 51, batch=8, step0=0)
+    s2 = MCMC_gpu.run_many(ch, rf, np.stack([r[0] for r in s1]), [5, 6, 7], 51, batch=8, step0=50)
+    for c in range(3):
+        assert np.array_equal(s2[c][0], a[c][0])
+        assert np.array_equal(np.concatenate([s1[c][4], s2[c][4][1:]]), a[c][4])
+
+
+def test_largeScaleChain_mp_philox_writes_reference_layout(tmp_path):
+    prob, ch, rf = synthetic.template(64)
+    ch.set_rng_mode("philox")
+    seeds = [111111, 222222, 333333]
+    beds = list(synthetic.initial_beds(prob, 3))
+    res = driver.largeScaleChain_mp(3, 7, ch, rf, beds, seeds, [1000] * 3, output_path=str(tmp_path))
+    res2 = driver.largeScaleChain_mp(3, 7, ch, rf, beds, seeds, [1000] * 3, output_path=str(tmp_path))
+    assert len(res) == 3 and len(res[0]) == 7
+    for s, r2 in zip(seeds, res2):
+        folder = tmp_path / "LargeScaleChain" / str(s)[:6]
+        assert int(np.loadtxt(folder / "current_iter.txt")) == 2000
+        assert np.array_equal(np.load(folder / "bed_2k.npy"), r2[0])
+        with np.load(folder / "results_2k.npz") as r:
+            assert r["loss"].shape == (2000,) and r["blocks_used"].shape == (2000, 4)
+        st = json.load(open(folder / "RNGState_philox.txt"))
+        assert st == {"key": s, "step": 1998}
+    # one unsplit philox run of the same total length gives the same final beds
+    one = MCMC_gpu.run_many(ch, rf, np.stack(beds), seeds, 1999, batch=8)
+    for a, b in zip(one, res2):
+        assert np.array_equal(a[0], b[0])
+
+
+def test_topography_residual_on_device(golden_dir):
+    g = np.load(golden_dir / "f5_residual.npz")
+    r = Topography.get_mass_conservation_residual(g["bed"], g["surf"], g["velx"], g["vely"], g["dhdt"], g["smb"],
+                                                  float(g["resolution"]))
+    assert isinstance(r, np.ndarray) and np.array_equal(r, g["residual"], equal_nan=True)
+    import torch
+    t = Topography.get_mass_conservation_residual_tensor(torch.tensor(g["bed"]), torch.tensor(g["surf"]),
+                                                         torch.tensor(g["velx"]), torch.tensor(g["vely"]),
+                                                         torch.tensor(g["dhdt"]), torch.tensor(g["smb"]),
+                                                         float(g["resolution"]))
+    assert t.is_cuda and np.array_equal(t.cpu().numpy(), g["residual"], equal_nan=True)
