@@ -51,7 +51,19 @@ typedef struct {
   double resolution;
   int32_t model;      /* GSM_MODEL_* */
   int32_t isotropic;  /* 1: one range draw shared by x and y (MCMC.py:207) */
+  int32_t generator;  /* GSM_GEN_SPECTRAL (reference's generator) or GSM_GEN_CHOLESKY (precomputed factors) */
+  int32_t reserved;
 } gsm_rf_params;
+
+enum { GSM_GEN_SPECTRAL = 0, GSM_GEN_CHOLESKY = 1 };
+enum { GSM_VTYPE_EXPONENTIAL = 0, GSM_VTYPE_GAUSSIAN = 1, GSM_VTYPE_SPHERICAL = 2, GSM_VTYPE_MATERN = 3 };
+
+/* Variogram of gstatsim_custom (the `vario` dict of _krige.py:83-122 / covariance.py:4-28). */
+typedef struct {
+  double azimuth, major_range, minor_range, sill, nugget, s;
+  int32_t vtype;      /* GSM_VTYPE_* */
+  int32_t reserved;
+} gsm_vario;
 
 /* Library / build identification: "gsm-hip <version> gfx950". */
 const char* gsm_version(void);
@@ -146,6 +158,27 @@ int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int32_t batch, 
 int gsm_enable_timing(gsm_handle h, int32_t on);
 int gsm_last_timing(gsm_handle h, double* step_kernel_ms, int32_t* step_launches,
                     double* proposal_kernel_ms, int32_t* proposal_launches);
+
+/* Dense covariance of the bh*bw cells of a block (cell a = i*bw + j at (x, y) = (j*res, i*res)):
+ * sigma[a*ld + b] = cov(|| (coord_a - coord_b) @ R ||) with R the anisotropy rotation/scaling matrix.
+ * lag_table [dev, (2bh-1)*(2bw-1)] is required for GSM_VTYPE_MATERN (values from scipy.special.kv, which is what
+ * covariance.py:17-22 evaluates) and optional otherwise.  sigma [dev, N*ld], ld >= N = bh*bw.
+ * Replaces: gstatsim_custom._krige.make_rotation_matrix / make_sigma (_krige.py:83-122) with the covariance
+ * models of gstatsim_custom/covariance.py:4-28 (incl. the spherical model's `sill - 1` beyond the range). */
+int gsm_cov_assemble(gsm_handle h, int32_t bh, int32_t bw, double resolution, const gsm_vario* vario,
+                     const double* lag_table, double* sigma, int64_t ld, void* stream);
+
+/* Precomputed factors of the Cholesky proposal generator: for block size i and range class r,
+ * factors[i*n_classes + r] [host array of dev pointers] is U = chol(Sigma + jitter I)^T, upper triangular,
+ * row-major [Npad][Npad] with Npad = N rounded up to 64 and zero padding.  The matrices stay caller-owned.
+ * With rf->generator == GSM_GEN_CHOLESKY, gsm_propose_philox / gsm_run_philox draw f = scale * (L z) * edge_mask
+ * (z ~ N(0, I) from Philox, size and range class uniform) instead of the spectral field.
+ * The reference has no such generator (README.md:21-23 lists it as future work); this is north_star's. */
+int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* const* factors, void* stream);
+
+/* Diagnostics: stream-copy n doubles src -> dst [dev] with the step kernel's access shape (8 bytes per lane,
+ * coalesced).  A known byte count for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM). */
+int gsm_debug_stream_copy(const double* src, double* dst, int64_t n, void* stream);
 
 /* Test hook: one Philox4x32-10 block on the host (ctr[4], key[2] -> out[4]); the device generator uses
  * the same inline function.  Checked against the Random123 known-answer vectors. */

@@ -16,7 +16,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libgsm_hip.so"
 HEADER = PKG_DIR.parent / "include" / "gsm.h"
-SOURCES = ["gsm_api.hip", "step_kernel.hip", "proposal_kernel.hip"]
+SOURCES = ["gsm_api.hip", "step_kernel.hip", "proposal_kernel.hip", "cholesky_kernel.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-unused-value", "-Wno-unused-result"]
 
@@ -66,7 +66,17 @@ class RfParams(C.Structure):
                 ("range_min_y", C.c_double), ("range_max_y", C.c_double),
                 ("scale_min", C.c_double), ("scale_max", C.c_double),
                 ("nugget_max", C.c_double), ("smoothness", C.c_double), ("resolution", C.c_double),
-                ("model", C.c_int32), ("isotropic", C.c_int32)]
+                ("model", C.c_int32), ("isotropic", C.c_int32), ("generator", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Vario(C.Structure):
+    """Mirror of gsm_vario (include/gsm.h)."""
+    _fields_ = [("azimuth", C.c_double), ("major_range", C.c_double), ("minor_range", C.c_double),
+                ("sill", C.c_double), ("nugget", C.c_double), ("s", C.c_double),
+                ("vtype", C.c_int32), ("reserved", C.c_int32)]
+
+
+VTYPE_IDS = {"exponential": 0, "gaussian": 1, "spherical": 2, "matern": 3}
 
 
 MODEL_IDS = {"Gaussian": 0, "Exponential": 1, "Matern": 2}
@@ -104,6 +114,9 @@ def load() -> C.CDLL:
     lib.gsm_run_philox.argtypes = [vp, i32, i64, i32, vp, C.POINTER(RfParams), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsm_enable_timing.argtypes = [vp, i32]
     lib.gsm_last_timing.argtypes = [vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(dbl), C.POINTER(i32)]
+    lib.gsm_cov_assemble.argtypes = [vp, i32, i32, dbl, C.POINTER(Vario), vp, vp, i64, vp]
+    lib.gsm_set_factors.argtypes = [vp, i32, C.POINTER(vp), vp]
+    lib.gsm_debug_stream_copy.argtypes = [vp, vp, i64, vp]
     lib.gsm_philox_selftest.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     for name in declared_symbols():
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch

@@ -26,6 +26,11 @@ struct gsm_context {
   int lds_sx = 0, lds_st = 0, lds_x_half = 0, lds_tt = 0, prop_tiles = 0, prop_tiles1 = 0;
   PropScalars* d_scalars[2] = {nullptr, nullptr};
   size_t scalars_cap[2] = {0, 0};
+  // Cholesky generator
+  int n_classes = 0;
+  const double** d_factors = nullptr;
+  struct CholScratch { int* ints = nullptr; int64_t* zoff = nullptr; int* per_rec = nullptr; double* scale = nullptr;
+                       double* zbuf = nullptr; size_t recs = 0; int groups = 0; } chol[2];
   BlockTable B{};
   int tile_cap = 0;
   int32_t* d_centres = nullptr;
@@ -114,6 +119,9 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_fy_off) hipFree(h->d_fy_off);
   if (h->d_g_off) hipFree(h->d_g_off);
   for (auto& p : h->d_scalars) if (p) hipFree(p);
+  if (h->d_factors) hipFree(h->d_factors);
+  for (auto& c : h->chol) { if (c.ints) hipFree(c.ints); if (c.zoff) hipFree(c.zoff); if (c.per_rec) hipFree(c.per_rec);
+                            if (c.scale) hipFree(c.scale); if (c.zbuf) hipFree(c.zbuf); }
   if (h->d_centres) hipFree(h->d_centres);
   if (h->d_err) hipFree(h->d_err);
   free_scratch(h);
@@ -346,6 +354,11 @@ static int check_propose_ready(gsm_handle h, const gsm_rf_params* rf, const char
   if (!h->have_blocks || !h->d_masks) return fail(h, GSM_E_STATE, std::string(who) + ": call gsm_set_blocks with edge masks first");
   if (!h->have_centres) return fail(h, GSM_E_STATE, std::string(who) + ": call gsm_set_centres first");
   if (!rf) return fail(h, GSM_E_ARG, std::string(who) + ": rf is NULL");
+  if (rf->generator == GSM_GEN_CHOLESKY) {
+    if (!h->d_factors) return fail(h, GSM_E_STATE, std::string(who) + ": call gsm_set_factors first");
+    return GSM_OK;
+  }
+  if (rf->generator != GSM_GEN_SPECTRAL) return fail(h, GSM_E_ARG, std::string(who) + ": unknown generator");
   if (rf->model < 0 || rf->model > 2) return fail(h, GSM_E_ARG, std::string(who) + ": unknown covariance model");
   if (!(rf->resolution > 0.0)) return fail(h, GSM_E_ARG, std::string(who) + ": rf.resolution must be > 0");
   if (rf->model == GSM_MODEL_MATERN && !(rf->smoothness > 0.0))
@@ -362,6 +375,26 @@ static int ensure_scalars(gsm_handle h, int slot, size_t recs) {
   if (h->d_scalars[slot]) { hipFree(h->d_scalars[slot]); h->d_scalars[slot] = nullptr; h->scalars_cap[slot] = 0; }
   HIPCHK(h, hipMalloc(&h->d_scalars[slot], recs * sizeof(PropScalars)));
   h->scalars_cap[slot] = recs;
+  return GSM_OK;
+}
+
+static int ensure_chol(gsm_handle h, int slot, size_t recs, CholArgs* out) {
+  auto& c = h->chol[slot];
+  const int groups = h->B.n_sizes * h->n_classes;
+  if (c.recs < recs || c.groups != groups) {
+    if (c.ints) { hipFree(c.ints); hipFree(c.zoff); hipFree(c.per_rec); hipFree(c.scale); hipFree(c.zbuf); c = gsm_context::CholScratch(); }
+    const size_t nmax_pad = (size_t)((h->B.max_bh * h->B.max_bw + 63) & ~63);
+    HIPCHK(h, hipMalloc(&c.ints, sizeof(int) * (size_t)(4 * groups + 2)));
+    HIPCHK(h, hipMalloc(&c.zoff, sizeof(int64_t) * (size_t)groups));
+    HIPCHK(h, hipMalloc(&c.per_rec, sizeof(int) * 2 * recs));
+    HIPCHK(h, hipMalloc(&c.scale, sizeof(double) * recs));
+    HIPCHK(h, hipMalloc(&c.zbuf, sizeof(double) * nmax_pad * (recs + (size_t)64 * groups)));
+    c.recs = recs; c.groups = groups;
+  }
+  out->n_classes = h->n_classes; out->n_groups = groups; out->factors = h->d_factors;
+  out->counts = c.ints; out->rec_off = c.ints + groups; out->tile_off = c.ints + 2 * groups + 1;
+  out->cursor = c.ints + 3 * groups + 2; out->z_off = c.zoff;
+  out->group_of = c.per_rec; out->order = c.per_rec + recs; out->scale = c.scale; out->zbuf = c.zbuf;
   return GSM_OK;
 }
 
@@ -390,7 +423,14 @@ extern "C" int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, 
   ProposeArgs p = make_propose(h, rf, n_steps, step0, seeds);
   p.size_idx = size_idx; p.centre = centre; p.u = u; p.fields = fields; p.field_stride = field_stride;
   p.rf_scalars = rf_scalars; p.scalars = h->d_scalars[0];
-  HIPCHK(h, launch_propose(p, (hipStream_t)stream));
+  if (rf->generator == GSM_GEN_CHOLESKY) {
+    CholArgs c{};
+    int rc2 = ensure_chol(h, 0, (size_t)h->n_chains * n_steps, &c);
+    if (rc2) return rc2;
+    HIPCHK(h, launch_propose_cholesky(p, c, (hipStream_t)stream));
+  } else {
+    HIPCHK(h, launch_propose(p, (hipStream_t)stream));
+  }
   return GSM_OK;
 }
 
@@ -458,6 +498,12 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
     p.size_idx = s.size_idx; p.centre = s.centre; p.u = s.u; p.fields = s.fields; p.field_stride = h->field_stride;
     p.rf_scalars = nullptr; p.scalars = h->d_scalars[k & 1];
     if (h->timing) HIPCHK(h, hipEventRecord(tev[4 * k], h->aux));
+    if (rf->generator == GSM_GEN_CHOLESKY) {
+      CholArgs c{};
+      int rc2 = ensure_chol(h, k & 1, recs, &c);
+      if (rc2) return rc2;
+      HIPCHK(h, launch_propose_cholesky(p, c, h->aux));
+    } else
     HIPCHK(h, launch_propose(p, h->aux));
     if (h->timing) HIPCHK(h, hipEventRecord(tev[4 * k + 1], h->aux));
     HIPCHK(h, hipEventRecord(h->ev_prop[k & 1], h->aux));
@@ -497,4 +543,41 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
     for (auto& e : tev) hipEventDestroy(e);
   }
   return rc;
+}
+
+extern "C" int gsm_debug_stream_copy(const double* src, double* dst, int64_t n, void* stream) {
+  if (!src || !dst || n < 0) return GSM_E_ARG;
+  return launch_stream_copy(src, dst, n, (hipStream_t)stream) == hipSuccess ? GSM_OK : GSM_E_HIP;
+}
+
+extern "C" int gsm_cov_assemble(gsm_handle h, int32_t bh, int32_t bw, double resolution, const gsm_vario* vario,
+                                const double* lag_table, double* sigma, int64_t ld, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!vario || !sigma || bh < 1 || bw < 1 || ld < (int64_t)bh * bw || ld > 0x7fffffff)
+    return fail(h, GSM_E_ARG, "gsm_cov_assemble: bad argument");
+  if (vario->vtype < 0 || vario->vtype > 3) return fail(h, GSM_E_ARG, "gsm_cov_assemble: unknown vtype");
+  if (vario->vtype == GSM_VTYPE_MATERN && !lag_table)
+    return fail(h, GSM_E_ARG, "gsm_cov_assemble: the Matern model needs the host-computed lag table (scipy.special.kv)");
+  if (!(vario->major_range > 0.0) || !(vario->minor_range > 0.0) || !(resolution > 0.0))
+    return fail(h, GSM_E_ARG, "gsm_cov_assemble: ranges and resolution must be > 0");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_cov_assemble(bh, bw, resolution, *vario, lag_table, sigma, (int)ld, (hipStream_t)stream));
+  return GSM_OK;
+}
+
+extern "C" int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* const* factors, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!h->have_blocks) return fail(h, GSM_E_STATE, "gsm_set_factors: call gsm_set_blocks first");
+  if (n_classes < 1 || !factors) return fail(h, GSM_E_ARG, "gsm_set_factors: bad argument");
+  const int groups = h->B.n_sizes * n_classes;
+  for (int g = 0; g < groups; ++g)
+    if (!factors[g]) return fail(h, GSM_E_ARG, "gsm_set_factors: NULL factor");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (h->d_factors) { hipFree(h->d_factors); h->d_factors = nullptr; }
+  HIPCHK(h, hipMalloc(&h->d_factors, sizeof(double*) * groups));
+  HIPCHK(h, hipMemcpyAsync(h->d_factors, factors, sizeof(double*) * groups, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  h->n_classes = n_classes;
+  return GSM_OK;
 }

@@ -97,7 +97,25 @@ struct ProposeArgs {
   int dbg;                 // diagnostics only (GSM_PROPOSE_DBG): bit0 cheap coefficients, bit1 skip stage 1, bit2 skip stage 2
 };
 
+// scratch + factor table of the Cholesky proposal generator (cholesky_kernel.hip)
+struct CholArgs {
+  int n_classes, n_groups;         // n_groups = n_sizes * n_classes
+  const double* const* factors;    // device array [n_groups] of U matrices
+  int* counts;                     // [n_groups]
+  int* rec_off;                    // [n_groups + 1]
+  int* tile_off;                   // [n_groups + 1]
+  int64_t* z_off;                  // [n_groups]
+  int* cursor;                     // [n_groups]
+  int* group_of;                   // [n_rec]
+  int* order;                      // [n_rec]
+  double* scale;                   // [n_rec]
+  double* zbuf;                    // sum over groups of Npad * ppad doubles
+};
+
 // launchers (defined next to their kernels)
+hipError_t launch_propose_cholesky(const ProposeArgs& a, const CholArgs& c, hipStream_t st);
+hipError_t launch_cov_assemble(int bh, int bw, double res, const gsm_vario& v, const double* lag_table, double* sigma,
+                               int ld, hipStream_t st);
 hipError_t launch_step(const StepArgs& a, hipStream_t st);
 hipError_t launch_init_loss(const StaticFields& S, int n_chains, const double* beds, double* energy,
                             double* loss_sum, double* loss0, hipStream_t st);
@@ -108,5 +126,6 @@ int propose_max_tiles_per_wave();
 int propose_max_tiles1_per_wave();
 int propose_waves();
 size_t step_lds_bytes(int tile_cap);
+hipError_t launch_stream_copy(const double* src, double* dst, int64_t n, hipStream_t st);
 
 }  // namespace gsm

@@ -44,7 +44,7 @@ GSM_HD u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
   return c;
 }
 
-enum : uint32_t { kStreamScalars = 0, kStreamSpectrum = 1, kStreamNugget = 2 };
+enum : uint32_t { kStreamScalars = 0, kStreamSpectrum = 1, kStreamNugget = 2, kStreamCholesky = 3 };
 
 GSM_HD u32x4 philox_draw(uint64_t seed, int64_t step, uint32_t stream, uint32_t idx) {
   u32x4 c;

@@ -369,6 +369,15 @@ hipError_t launch_pack_static(const StaticFields& S, double2* svx, double2* svy,
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(kBlock) void stream_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) dst[i] = src[i];
+}
+
+hipError_t launch_stream_copy(const double* src, double* dst, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(stream_copy_kernel, dim3(2048), dim3(kBlock), 0, st, src, dst, n);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Topography.get_mass_conservation_residual for a batch of beds (Topography.py:592-600)
 // ---------------------------------------------------------------------------------------------------

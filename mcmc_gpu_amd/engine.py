@@ -210,6 +210,7 @@ class GsmEngine:
         p.resolution = float(resolution if resolution is not None else rf.resolution)
         p.model = MODEL_IDS[rf.model_name]
         p.isotropic = 1 if rf.isotropic else 0
+        p.generator = 1 if getattr(rf, "generator", "spectral") == "cholesky" else 0
         return p
 
     def _seeds(self, seeds):
