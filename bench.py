@@ -30,6 +30,20 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak
+
+
+def pmc_traffic(H, n_chains, batch):
+    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of scripts/pmc_run.py, calibrated on a stream copy
+    of known size with the same 8-byte-per-lane access shape).  None when no measurement matches this config."""
+    try:
+        d = json.load(open(ROOT / "profiles" / "pmc_traffic.json"))
+        if (d["grid"], d["chains"], d["steps_per_launch"]) == (H, n_chains, batch):
+            return d["step_kernel_hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def algorithmic_bytes(blocks, accept, H, W, state_bytes=8):
@@ -99,6 +113,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--gather-beds", action="store_true", help="also all-gather the final beds (512 MiB per GPU at 256^2)")
+    ap.add_argument("--generator", choices=["spectral", "cholesky"], default="spectral",
+                    help="proposal generator: the reference's spectral synthesis (headline) or precomputed Cholesky factors (BASELINE configs[3])")
+    ap.add_argument("--classes", type=int, default=2, help="range classes of the Cholesky generator")
     args = ap.parse_args()
 
     from mcmc_gpu_amd import parallel, synthetic
@@ -123,6 +140,10 @@ def main():
     eng.set_state(beds0)
     del beds0
     eng.enable_timing(True)
+    if args.generator == "cholesky":
+        from mcmc_gpu_amd import cholesky as chol
+        rf.generator = "cholesky"
+        chol.build_factors(eng, rf, n_classes=args.classes)
     p = eng.rf_struct(rf)
     inner, batch = args.inner, args.batch
     n_timed = args.steps * inner
@@ -179,20 +200,33 @@ def main():
         dom = "step_kernel" if t_step >= t_prop else "propose_kernel"
         dom_ms = step_ms if dom == "step_kernel" else prop_ms
         achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(H, n_local, batch), "kernel": dom,
+                "algorithmic_bytes_per_chain_step": bytes_total / (n_local * n_timed),
+                "bytes_per_launch": bytes_per_launch,
+                "step_kernel_ms": step_ms, "propose_kernel_ms": prop_ms, "launches": n_step_l}
+        if args.generator == "cholesky":
+            # algorithmic flops per chain-step = (bh*bw)^2 (lower-triangular L z)
+            nn = (blocks_h[..., 2].astype(np.float64) * blocks_h[..., 3]) ** 2
+            flops_per_launch = float(nn.sum()) / max(n_prop_l, 1)
+            ach = flops_per_launch / (prop_ms * 1e-3) / 1e12 if prop_ms > 0 else 0.0
+            roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / MFMA_F64_PEAK_TFLOPS, "traffic": None, "kernel": "cz_* proposal pipeline (zgen + gemm)",
+                    "algorithmic_flops_per_chain_step": float(nn.mean()), "flops_per_launch": flops_per_launch,
+                    "step_kernel_ms": step_ms, "propose_kernel_ms": prop_ms, "launches": n_prop_l}
         out = {
             "metric": "chain-steps/sec on 256x256 grid x 1024 chains; accept-rate parity",
             "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"largeScaleChain {H}x{H} grid, {n_local} chains/GPU, fp64, Philox spectral (Matern 0.9125) "
-                                   f"proposals, blocks 50-80, sigma_mc 5 (BASELINE configs[1])",
+            "config": {"workload": f"largeScaleChain {H}x{H} grid, {n_local} chains/GPU, fp64, Philox "
+                                   + ("spectral (Matern 0.9125) proposals, blocks 50-80, sigma_mc 5 (BASELINE configs[1])"
+                                      if args.generator == "spectral" else
+                                      f"precomputed-Cholesky (Matern 0.9125, {args.classes} range classes) proposals, "
+                                      "blocks 50-80, sigma_mc 5 (BASELINE configs[3])"),
                        "chains_total": n_total, "mh_steps_per_bench_step": inner, "steps_per_launch": batch},
             "accept_rate": h_acc_rate, "final_loss_mean": float(h_loss.mean()),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
-                         "algorithmic_bytes_per_chain_step": bytes_total / (n_local * n_timed),
-                         "bytes_per_launch": bytes_per_launch,
-                         "step_kernel_ms": step_ms, "propose_kernel_ms": prop_ms, "launches": n_step_l},
+            "roofline": roof,
         }
         if cpu_res is not None:
             out["cpu_baseline"] = cpu_res
