@@ -53,7 +53,7 @@ def algorithmic_bytes(blocks, accept, H, W, state_bytes=8):
     c0 = np.maximum(0, col - bw // 2); c1 = np.minimum(W, col + bw // 2)
     beff = (r1 - r0) * (c1 - c0)
     a = accept.astype(np.int64)
-    return int((state_bytes * 2 * beff + a * (state_bytes * 2 * beff + 8 * beff)).sum())
+    return int((state_bytes * 2 * beff + a * (state_bytes * 2 * beff + 8 * beff)).sum())  # s = 8 (f64) or 4 (f32)
 
 
 def _cpu_worker(args):
@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--generator", choices=["spectral", "cholesky"], default="spectral",
                     help="proposal generator: the reference's spectral synthesis (headline) or precomputed Cholesky factors (BASELINE configs[3])")
     ap.add_argument("--classes", type=int, default=2, help="range classes of the Cholesky generator")
+    ap.add_argument("--state", choices=["f64", "f32"], default="f64",
+                    help="per-chain state storage: f64 (headline) or f32 with f64 arithmetic (BASELINE configs[4])")
     args = ap.parse_args()
 
     from mcmc_gpu_amd import parallel, synthetic
@@ -134,6 +136,7 @@ def main():
     n_local = args.chains
     n_total = n_local * world
     prob, ch, rf = synthetic.template(H)
+    ch.state_dtype = args.state
     beds0 = synthetic.initial_beds(prob, n_local, first=rank * n_local)
     seeds = [7 + rank * n_local + i for i in range(n_local)]
     eng = ch._make_engine(rf, n_local, dev_index)
@@ -158,7 +161,7 @@ def main():
         """Per-chain caches to every rank, posterior-mean field, small results to the host."""
         g_loss = parallel.all_gather_chains(loss_all, n_total)
         g_acc = parallel.all_gather_chains(acc_all, n_total)
-        mean_field = parallel.all_reduce_mean_field(eng.beds.sum(dim=0), n_total)
+        mean_field = parallel.all_reduce_mean_field(eng.beds.sum(dim=0, dtype=torch.float64), n_total)
         if args.gather_beds:
             parallel.all_gather_chains(eng.beds, n_total)
         return g_loss[:, -1].cpu(), float(g_acc.float().mean().item()), mean_field.cpu()
@@ -194,7 +197,7 @@ def main():
     value = chain_steps / elapsed
     if rank == 0:
         blocks_h = blk_all.cpu().numpy(); acc_h = acc_all.cpu().numpy()
-        bytes_total = algorithmic_bytes(blocks_h, acc_h, H, H)
+        bytes_total = algorithmic_bytes(blocks_h, acc_h, H, H, 8 if args.state == "f64" else 4)
         bytes_per_launch = bytes_total / max(n_step_l, 1)
         step_ms = t_step / max(n_step_l, 1); prop_ms = t_prop / max(n_prop_l, 1)
         dom = "step_kernel" if t_step >= t_prop else "propose_kernel"
@@ -218,8 +221,8 @@ def main():
             "metric": "chain-steps/sec on 256x256 grid x 1024 chains; accept-rate parity",
             "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"largeScaleChain {H}x{H} grid, {n_local} chains/GPU, fp64, Philox "
+            "vs_baseline": None, "dtype": "f64" if args.state == "f64" else "f64 arithmetic on f32 state", "data": "synthetic",
+            "config": {"workload": f"largeScaleChain {H}x{H} grid, {n_local} chains/GPU, {'fp64' if args.state == 'f64' else 'fp32 state / fp64 arithmetic'}, Philox "
                                    + ("spectral (Matern 0.9125) proposals, blocks 50-80, sigma_mc 5 (BASELINE configs[1])"
                                       if args.generator == "spectral" else
                                       f"precomputed-Cholesky (Matern 0.9125, {args.classes} range classes) proposals, "

@@ -15,7 +15,9 @@
  *     exception crosses the ABI.  A handle is not thread-safe; distinct handles are independent.
  *   - "stream" is a hipStream_t passed as void* (0 = the null stream).  Kernels are enqueued on it and
  *     the call returns without synchronising unless stated.
- *   - Grids are H rows x W columns, fp64.  Chain c's bed is beds + c*H*W.
+ *   - Grids are H rows x W columns.  Static fields are fp64; the per-chain state (beds, energy) is fp64, or
+ *     fp32 for a handle created with dtype 1 (then `void* beds` / `void* energy` point to float arrays).
+ *     Chain c's bed starts at element c*H*W.
  *
  * Layout of per-step records, for chain c and step s of a call with n_steps steps: index c*n_steps+s.
  */
@@ -72,7 +74,9 @@ const char* gsm_version(void);
 const char* gsm_last_error(gsm_handle h);
 
 /* Create a sampler for n_chains chains on an H x W grid on HIP device `device`.
- * dtype: 0 = fp64 state (the only one this build serves).
+ * dtype: 0 = fp64 state; 1 = fp32 state with fp64 arithmetic (beds and energy are float arrays; every value is
+ * rounded to float before it is used, so the carried loss sum always equals the sum of what is stored --
+ * BASELINE configs[4]; the reference's torch class is all-fp32, MCMC_gpu.py:261).
  * Replaces: the per-process chain construction of lsc_run_wrapper
  * (largeScaleChain_multiprocessing_GPU.py:126-127) -- one handle holds all chains of one GPU. */
 int gsm_create(gsm_handle* out, int32_t H, int32_t W, int32_t n_chains, int32_t dtype, int32_t device);
@@ -109,7 +113,7 @@ int gsm_set_centres(gsm_handle h, const int32_t* cells, int32_t n_cells, void* s
  * loss0    [dev, n_chains] (may be NULL): sum / (2 sigma^2) = loss_cache[0].
  * Replaces: MCMC.py:1189-1195 (Topography.get_mass_conservation_residual, Topography.py:592-600,
  * and chain.loss, MCMC.py:1021-1044). */
-int gsm_init_loss(gsm_handle h, const double* beds, double* energy, double* loss_sum, double* loss0, void* stream);
+int gsm_init_loss(gsm_handle h, const void* beds, void* energy, double* loss_sum, double* loss0, void* stream);
 
 /* Full-grid residual of chain beds [dev, n_chains*H*W] -> residual [dev, same shape].
  * Replaces: Topography.get_mass_conservation_residual (Topography.py:592-600). */
@@ -125,7 +129,7 @@ int gsm_residual(gsm_handle h, const double* beds, double* residual, void* strea
  * (loss_cache entries), accept [n_chains*n_steps] (0/1).
  * Synchronises the stream before returning (it reports out-of-range device data as GSM_E_DEVICE_DATA).
  * Replaces: the loop body of chain_crf.run, MCMC.py:1263-1360 (torch twin MCMC_gpu.py:385-494). */
-int gsm_run_replay(gsm_handle h, int32_t n_steps, double* beds, double* energy, uint32_t* resampled, double* loss_sum,
+int gsm_run_replay(gsm_handle h, int32_t n_steps, void* beds, void* energy, uint32_t* resampled, double* loss_sum,
                    const int32_t* size_idx, const int32_t* centre, const double* u,
                    const double* fields, int64_t field_stride,
                    double* loss, uint8_t* accept, void* stream);
@@ -149,7 +153,7 @@ int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, const uint6
  * Replaces: chain_crf.run for a whole shard of chains (MCMC.py:1137-1443) as called from
  * lsc_run_wrapper (largeScaleChain_multiprocessing_GPU.py:194-201). */
 int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int32_t batch, const uint64_t* seeds,
-                   const gsm_rf_params* rf, double* beds, double* energy, uint32_t* resampled, double* loss_sum,
+                   const gsm_rf_params* rf, void* beds, void* energy, uint32_t* resampled, double* loss_sum,
                    double* loss, uint8_t* accept, int32_t* blocks, void* stream);
 
 /* Average duration in milliseconds of the step kernel / the proposal kernel over the launches made

@@ -189,6 +189,7 @@ class chain_crf_gpu:
         self.replay_chunk = 256
         self.philox_step = 0
         self.philox_batch = 8
+        self.state_dtype = 'f64'   # 'f32': float32 bed/energy storage with float64 arithmetic (BASELINE configs[4])
 
     # ---- setters (MCMC.py:849-872, :950-1018, :1046-1081, :1098-1134) ---------------------------
     def set_update_region(self, update_in_region, region_mask=[]):
@@ -243,7 +244,7 @@ class chain_crf_gpu:
     def _make_engine(self, RF, n_chains, device=None):
         from .engine import GsmEngine
         H, W = self.xx.shape
-        eng = GsmEngine(H, W, n_chains, device)
+        eng = GsmEngine(H, W, n_chains, device, state_dtype=getattr(self, 'state_dtype', 'f64'))
         upd = self.region_mask if self.update_in_region else self.grounded_ice_mask
         weight = self.crf_data_weight if self.block_type == 'CRF_weight' else None
         eng.set_static(self.surf, self.velx, self.vely, self.dhdt, self.smb, weight, upd, self.mc_region_mask,
@@ -348,7 +349,7 @@ class chain_crf_gpu:
                 loss_cache[done:done + n] = loss[0]
                 step_cache[done:done + n] = acc[0]
                 if per_step:
-                    b = eng.beds[0].cpu().numpy()
+                    b = eng.beds[0].double().cpu().numpy()
                     if keep_all:
                         bed_cache[done] = b
                     if track:
@@ -361,7 +362,7 @@ class chain_crf_gpu:
                           f"{100 * (done - 1) / max(n_iter - 1, 1):3.0f}% | it/s: {(done - 1) / max(el, 1e-9):8.1f} | "
                           f"n: {n_iter} | loss: {loss_cache[done - 1]:.3e} | acc: {step_cache[:done].sum() / done:.4f}",
                           file=sys.stdout, flush=True)
-            bed_c = eng.beds[0].cpu().numpy()
+            bed_c = eng.beds[0].double().cpu().numpy()
             resampled = eng.resampled[0].cpu().numpy().astype(np.float64)
         finally:
             eng.close()
@@ -391,7 +392,7 @@ def run_many(chain, RF, initial_beds, seeds, n_iter, batch=8, device=None, step0
             loss = np.zeros((n_chains, 0)); acc = np.zeros((n_chains, 0), np.uint8); blk = np.zeros((n_chains, 0, 4), np.int32)
         if return_device:
             return eng, loss0, loss, acc, blk
-        beds_out = eng.beds.cpu().numpy()
+        beds_out = eng.beds.double().cpu().numpy()
         res = eng.resampled.cpu().numpy().astype(np.float64)
     finally:
         if not return_device:
@@ -419,7 +420,7 @@ def init_lsc_chain_by_instance(param_dict):
     ch.rng_seed = p['rng_seed']
     ch.mc_region_mask = p['mc_region_mask']
     ch.sample_loc = deepcopy(p['sample_loc'])
-    for k in ('rng_mode', 'replay_chunk', 'philox_step', 'philox_batch'):
+    for k in ('rng_mode', 'replay_chunk', 'philox_step', 'philox_batch', 'state_dtype'):
         if k in p:
             setattr(ch, k, p[k])
     return ch

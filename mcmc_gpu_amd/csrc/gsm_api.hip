@@ -9,7 +9,7 @@
 using namespace gsm;
 
 struct gsm_context {
-  int H = 0, W = 0, n_chains = 0, device = 0;
+  int H = 0, W = 0, n_chains = 0, device = 0, f32_state = 0;
   std::string err;
   bool have_static = false, have_blocks = false, have_centres = false;
   // owned device copies
@@ -75,7 +75,7 @@ extern "C" int gsm_create(gsm_handle* out, int32_t H, int32_t W, int32_t n_chain
   *out = nullptr;
   if (H < 3 || W < 3 || n_chains < 1) return fail(nullptr, GSM_E_ARG, "gsm_create: need H,W >= 3 and n_chains >= 1");
   if ((int64_t)H * W > (1LL << 30)) return fail(nullptr, GSM_E_ARG, "gsm_create: grid too large");
-  if (dtype != 0) return fail(nullptr, GSM_E_UNSUPPORTED, "gsm_create: only dtype 0 (fp64 state) is built");
+  if (dtype != 0 && dtype != 1) return fail(nullptr, GSM_E_UNSUPPORTED, "gsm_create: dtype must be 0 (fp64 state) or 1 (fp32 state)");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev < 1)
@@ -84,7 +84,7 @@ extern "C" int gsm_create(gsm_handle* out, int32_t H, int32_t W, int32_t n_chain
   e = hipSetDevice(device);
   if (e != hipSuccess) return fail(nullptr, GSM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
   gsm_context* c = new gsm_context();
-  c->H = H; c->W = W; c->n_chains = n_chains; c->device = device;
+  c->H = H; c->W = W; c->n_chains = n_chains; c->device = device; c->f32_state = dtype;
   e = hipMalloc(&c->d_err, sizeof(int32_t));
   if (e == hipSuccess) e = hipMemset(c->d_err, 0, sizeof(int32_t));
   if (e != hipSuccess) { delete c; return fail(nullptr, GSM_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -294,12 +294,12 @@ extern "C" int gsm_set_centres(gsm_handle h, const int32_t* cells, int32_t n_cel
   return GSM_OK;
 }
 
-extern "C" int gsm_init_loss(gsm_handle h, const double* beds, double* energy, double* loss_sum, double* loss0, void* stream) {
+extern "C" int gsm_init_loss(gsm_handle h, const void* beds, void* energy, double* loss_sum, double* loss0, void* stream) {
   if (!h) return GSM_E_ARG;
   if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_init_loss: call gsm_set_static first");
   if (!beds || !energy || !loss_sum) return fail(h, GSM_E_ARG, "gsm_init_loss: NULL pointer");
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, launch_init_loss(h->S, h->n_chains, beds, energy, loss_sum, loss0, (hipStream_t)stream));
+  HIPCHK(h, launch_init_loss(h->S, h->n_chains, beds, energy, h->f32_state, loss_sum, loss0, (hipStream_t)stream));
   return GSM_OK;
 }
 
@@ -307,6 +307,7 @@ extern "C" int gsm_residual(gsm_handle h, const double* beds, double* residual, 
   if (!h) return GSM_E_ARG;
   if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_residual: call gsm_set_static first");
   if (!beds || !residual) return fail(h, GSM_E_ARG, "gsm_residual: NULL pointer");
+  if (h->f32_state) return fail(h, GSM_E_UNSUPPORTED, "gsm_residual: fp64 beds only (create the handle with dtype 0)");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, launch_residual(h->S, h->n_chains, beds, residual, (hipStream_t)stream));
   return GSM_OK;
@@ -324,7 +325,7 @@ static int check_device_flag(gsm_handle h, hipStream_t st, const char* who) {
   return GSM_OK;
 }
 
-extern "C" int gsm_run_replay(gsm_handle h, int32_t n_steps, double* beds, double* energy, uint32_t* resampled, double* loss_sum,
+extern "C" int gsm_run_replay(gsm_handle h, int32_t n_steps, void* beds, void* energy, uint32_t* resampled, double* loss_sum,
                               const int32_t* size_idx, const int32_t* centre, const double* u,
                               const double* fields, int64_t field_stride, double* loss, uint8_t* accept,
                               void* stream) {
@@ -341,7 +342,7 @@ extern "C" int gsm_run_replay(gsm_handle h, int32_t n_steps, double* beds, doubl
   StepArgs a{};
   a.S = h->S; a.B = h->B;
   a.n_chains = h->n_chains; a.n_steps = n_steps; a.tile_cap = h->tile_cap;
-  a.beds = beds; a.energy = energy; a.resampled = resampled; a.loss_sum = loss_sum;
+  a.beds = beds; a.energy = energy; a.f32_state = h->f32_state; a.resampled = resampled; a.loss_sum = loss_sum;
   a.size_idx = size_idx; a.centre = centre; a.u = u; a.fields = fields; a.field_stride = field_stride;
   a.loss = loss; a.accept = accept; a.blocks = nullptr;
   a.rec_stride = n_steps; a.rec_offset = 0; a.in_stride = n_steps;
@@ -450,7 +451,7 @@ extern "C" int gsm_last_timing(gsm_handle h, double* step_ms, int32_t* step_laun
 }
 
 extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int32_t batch, const uint64_t* seeds,
-                              const gsm_rf_params* rf, double* beds, double* energy, uint32_t* resampled, double* loss_sum,
+                              const gsm_rf_params* rf, void* beds, void* energy, uint32_t* resampled, double* loss_sum,
                               double* loss, uint8_t* accept, int32_t* blocks, void* stream) {
   if (!h) return GSM_E_ARG;
   if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_run_philox: call gsm_set_static first");
@@ -520,7 +521,7 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
     StepArgs a{};
     a.S = h->S; a.B = h->B;
     a.n_chains = h->n_chains; a.n_steps = nb; a.tile_cap = h->tile_cap;
-    a.beds = beds; a.energy = energy; a.resampled = resampled; a.loss_sum = loss_sum;
+    a.beds = beds; a.energy = energy; a.f32_state = h->f32_state; a.resampled = resampled; a.loss_sum = loss_sum;
     a.size_idx = s.size_idx; a.centre = s.centre; a.u = s.u; a.fields = s.fields; a.field_stride = h->field_stride;
     a.loss = loss; a.accept = accept; a.blocks = blocks;
     a.rec_stride = n_steps; a.rec_offset = (int64_t)k * batch; a.in_stride = nb;

@@ -45,8 +45,9 @@ struct StepArgs {
   BlockTable B;
   int n_chains, n_steps;
   int tile_cap;           // doubles available for the LDS tile
-  double* beds;
-  double* energy;         // [n_chains][H][W] masked squared residual of the current bed (0 where not counted)
+  void* beds;             // [n_chains][H][W] double, or float when f32_state
+  void* energy;           // [n_chains][H][W] masked squared residual of the current bed (0 where not counted)
+  int f32_state;
   uint32_t* resampled;
   double* loss_sum;       // [n_chains][2]
   const int32_t* size_idx;
@@ -117,7 +118,7 @@ hipError_t launch_propose_cholesky(const ProposeArgs& a, const CholArgs& c, hipS
 hipError_t launch_cov_assemble(int bh, int bw, double res, const gsm_vario& v, const double* lag_table, double* sigma,
                                int ld, hipStream_t st);
 hipError_t launch_step(const StepArgs& a, hipStream_t st);
-hipError_t launch_init_loss(const StaticFields& S, int n_chains, const double* beds, double* energy,
+hipError_t launch_init_loss(const StaticFields& S, int n_chains, const void* beds, void* energy, int f32_state,
                             double* loss_sum, double* loss0, hipStream_t st);
 hipError_t launch_pack_static(const StaticFields& S, double2* svx, double2* svy, double2* ds, hipStream_t st);
 hipError_t launch_residual(const StaticFields& S, int n_chains, const double* beds, double* out, hipStream_t st);

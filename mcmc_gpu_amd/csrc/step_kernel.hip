@@ -83,8 +83,11 @@ __device__ __forceinline__ void two_sum(double a, double b, double& s, double& e
 // ---------------------------------------------------------------------------------------------------
 // step kernel.  NT threads per workgroup, KMAX = ceil(max window cells / NT) window cells per thread.
 // ---------------------------------------------------------------------------------------------------
-template <int NT, int KMAX, bool FAST_DIV, int MINW>
+// TS = state element type: double, or float ("fp32 state, fp64 arithmetic": the candidate bed and the new
+// energies are rounded to float BEFORE they are used, so the carried sum always equals the sum of what is stored).
+template <typename TS, int NT, int KMAX, bool FAST_DIV, int MINW>
 __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
+  constexpr bool F32 = sizeof(TS) == 4;
   constexpr int NW = NT / 64;
   extern __shared__ double lds[];
   double* tile = lds;
@@ -96,8 +99,8 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
   const int chain = blockIdx.x;
   const int H = S.H, W = S.W;
   const size_t plane = (size_t)H * W;
-  double* __restrict__ bed = a.beds + (size_t)chain * plane;
-  double* __restrict__ energy = a.energy + (size_t)chain * plane;
+  TS* __restrict__ bed = (TS*)a.beds + (size_t)chain * plane;
+  TS* __restrict__ energy = (TS*)a.energy + (size_t)chain * plane;
   uint32_t* __restrict__ resamp = a.resampled + (size_t)chain * plane;
   const double2* __restrict__ svx = S.svx;
   const double2* __restrict__ svy = S.svy;
@@ -145,14 +148,15 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
       const int lr = (int)__umulhi((uint32_t)i, m_tw);
       const int lc = i - lr * tw;
       const int g = (hr0 + lr) * W + hc0 + lc;
-      double v = bed[g];
+      double v = (double)bed[g];
       const int wr = lr - dr, wc = lc - dc;
       if ((unsigned)wr < (unsigned)wh && (unsigned)wc < (unsigned)ww) {
-        acc_old += energy[g];
+        acc_old += (double)energy[g];
         if (S.upd[g]) {
           const double f = fld[(mr0 + wr) * bw + mc0 + wc];
           const double pert = S.weight ? f * S.weight[g] : f;
           v = v + pert;
+          if (F32) v = (double)(float)v;
           if (svx[g].x - v <= 0.0) guard = 1;
         }
       }
@@ -193,6 +197,7 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
           }
           const double v = ((dx + dy) + dd.x) - dd.y;
           if (!isnan(v)) e = v * v;
+          if (F32) e = (double)(float)e;
         }
       }
       e_new[k] = e;
@@ -230,9 +235,9 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
           const int wc = i - wr * ww;
           const int r = r0 + wr, c = c0 + wc;
           const size_t g = (size_t)r * W + c;
-          energy[g] = e_new[k];
+          energy[g] = (TS)e_new[k];
           if (S.upd[g]) {
-            bed[g] = tile[(r - hr0) * tw + (c - hc0)];
+            bed[g] = (TS)tile[(r - hr0) * tw + (c - hc0)];
             resamp[g] += 1u;
           }
         }
@@ -255,11 +260,11 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
 
 size_t step_lds_bytes(int tile_cap) { return ((size_t)tile_cap + 3 * 16) * sizeof(double); }
 
-template <int NT, int KMAX, int MINW>
+template <typename TS, int NT, int KMAX, int MINW>
 static hipError_t launch_step_t(const StepArgs& a, hipStream_t st) {
   const size_t lds = step_lds_bytes(a.tile_cap);
-  auto kfast = step_kernel<NT, KMAX, true, MINW>;
-  auto kslow = step_kernel<NT, KMAX, false, MINW>;
+  auto kfast = step_kernel<TS, NT, KMAX, true, MINW>;
+  auto kslow = step_kernel<TS, NT, KMAX, false, MINW>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kfast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -277,17 +282,21 @@ hipError_t launch_step(const StepArgs& a, hipStream_t st) {
   const int max_win = a.B.max_bh * a.B.max_bw;
   static int variant = -1;
   if (variant < 0) { const char* v = getenv("GSM_STEP_VARIANT"); variant = v ? atoi(v) : 1; }
+  if (a.f32_state) {
+    if (max_win <= 1024 * 7) return launch_step_t<float, 1024, 7, 8>(a, st);
+    if (max_win <= 1024 * 12) return launch_step_t<float, 1024, 12, 4>(a, st);
+    if (max_win <= 1024 * 20) return launch_step_t<float, 1024, 20, 4>(a, st);
+    return hipErrorInvalidValue;
+  }
   if (max_win <= 1024 * 7) {
     switch (variant) {
-      case 0: return launch_step_t<1024, 7, 4>(a, st);
-      case 2: return launch_step_t<512, 13, 4>(a, st);
-      case 3: return launch_step_t<512, 13, 6>(a, st);    // <=80 VGPRs: 3 workgroups per CU
-      case 4: return launch_step_t<256, 25, 2>(a, st);
-      default: return launch_step_t<1024, 7, 8>(a, st);   // <=64 VGPRs: 2 workgroups per CU (fastest measured)
+      case 0: return launch_step_t<double, 1024, 7, 4>(a, st);
+      case 2: return launch_step_t<double, 512, 13, 4>(a, st);
+      default: return launch_step_t<double, 1024, 7, 8>(a, st);   // <=64 VGPRs: 2 workgroups per CU (fastest measured)
     }
   }
-  if (max_win <= 1024 * 12) return launch_step_t<1024, 12, 4>(a, st);
-  if (max_win <= 1024 * 20) return launch_step_t<1024, 20, 4>(a, st);
+  if (max_win <= 1024 * 12) return launch_step_t<double, 1024, 12, 4>(a, st);
+  if (max_win <= 1024 * 20) return launch_step_t<double, 1024, 20, 4>(a, st);
   return hipErrorInvalidValue;  // gsm_set_blocks refuses such tables (LDS tile limit is reached first)
 }
 
@@ -297,14 +306,15 @@ hipError_t launch_step(const StepArgs& a, hipStream_t st) {
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 
-__global__ __launch_bounds__(kBlock) void init_loss_kernel(const StaticFields S, const double* beds, double* energy,
+template <typename TS>
+__global__ __launch_bounds__(kBlock) void init_loss_kernel(const StaticFields S, const TS* beds, TS* energy,
                                                            double* loss_sum, double* loss0) {
   __shared__ double red[kWaves * 2];
   const int chain = blockIdx.x, tid = threadIdx.x;
   const size_t plane = (size_t)S.H * S.W;
-  const double* bed = beds + (size_t)chain * plane;
-  double* en = energy ? energy + (size_t)chain * plane : nullptr;
-  auto bed_at = [&](int rr, int cc) { return bed[(size_t)rr * S.W + cc]; };
+  const TS* bed = beds + (size_t)chain * plane;
+  TS* en = energy ? energy + (size_t)chain * plane : nullptr;
+  auto bed_at = [&](int rr, int cc) { return (double)bed[(size_t)rr * S.W + cc]; };
   // per-thread compensated partial
   double hi = 0.0, lo = 0.0;
   for (int g = tid; g < (int)plane; g += kBlock) {
@@ -313,8 +323,9 @@ __global__ __launch_bounds__(kBlock) void init_loss_kernel(const StaticFields S,
       const int r = g / S.W, c = g - r * S.W;
       const double v = cell_residual(S, r, c, bed_at);
       if (!isnan(v)) e = v * v;
+      if (sizeof(TS) == 4) e = (double)(float)e;
     }
-    if (en) en[g] = e;
+    if (en) en[g] = (TS)e;
     double s, err;
     two_sum(hi, e, s, err);
     hi = s;
@@ -347,9 +358,12 @@ __global__ __launch_bounds__(kBlock) void init_loss_kernel(const StaticFields S,
   }
 }
 
-hipError_t launch_init_loss(const StaticFields& S, int n_chains, const double* beds, double* energy,
+hipError_t launch_init_loss(const StaticFields& S, int n_chains, const void* beds, void* energy, int f32_state,
                             double* loss_sum, double* loss0, hipStream_t st) {
-  hipLaunchKernelGGL(init_loss_kernel, dim3(n_chains), dim3(kBlock), 0, st, S, beds, energy, loss_sum, loss0);
+  if (f32_state)
+    hipLaunchKernelGGL(init_loss_kernel<float>, dim3(n_chains), dim3(kBlock), 0, st, S, (const float*)beds, (float*)energy, loss_sum, loss0);
+  else
+    hipLaunchKernelGGL(init_loss_kernel<double>, dim3(n_chains), dim3(kBlock), 0, st, S, (const double*)beds, (double*)energy, loss_sum, loss0);
   return hipGetLastError();
 }
 

@@ -29,7 +29,7 @@ def binary_mask(mask, name):
 
 
 class GsmEngine:
-    def __init__(self, H: int, W: int, n_chains: int, device: int | None = None):
+    def __init__(self, H: int, W: int, n_chains: int, device: int | None = None, state_dtype="f64"):
         if not torch.cuda.is_available():
             raise RuntimeError("no ROCm/HIP device visible to torch: the sampler has no CPU fallback")
         self.lib = _lib.load()
@@ -37,7 +37,11 @@ class GsmEngine:
         self.device_index = torch.cuda.current_device() if device is None else int(device)
         self.dev = torch.device("cuda", self.device_index)
         h = C.c_void_p()
-        rc = self.lib.gsm_create(C.byref(h), self.H, self.W, self.n_chains, 0, self.device_index)
+        if state_dtype not in ("f64", "f32"):
+            raise ValueError("state_dtype must be 'f64' or 'f32'")
+        self.state_dtype = torch.float64 if state_dtype == "f64" else torch.float32
+        rc = self.lib.gsm_create(C.byref(h), self.H, self.W, self.n_chains, 0 if state_dtype == "f64" else 1,
+                                 self.device_index)
         if rc != 0:
             raise GsmError(rc, self.lib.gsm_last_error(None).decode())
         self.h = h
@@ -126,9 +130,9 @@ class GsmEngine:
     def set_state(self, beds, resampled=None):
         """beds: (n_chains, H, W) array or cuda tensor.  Returns loss_cache[0] per chain (numpy)."""
         if isinstance(beds, torch.Tensor):
-            b = beds.to(device=self.dev, dtype=torch.float64).contiguous()
+            b = beds.to(device=self.dev, dtype=self.state_dtype).contiguous()
         else:
-            b = self._f64(beds)
+            b = self._f64(beds).to(self.state_dtype)
         if tuple(b.shape) != (self.n_chains, self.H, self.W):
             raise ValueError(f"beds must have shape {(self.n_chains, self.H, self.W)}, got {tuple(b.shape)}")
         self.beds = b
@@ -137,7 +141,7 @@ class GsmEngine:
         else:
             self.resampled = torch.as_tensor(resampled).to(device=self.dev, dtype=torch.int32).contiguous()
         self.loss_sum = torch.zeros((self.n_chains, 2), dtype=torch.float64, device=self.dev)
-        self.energy = torch.empty((self.n_chains, self.H, self.W), dtype=torch.float64, device=self.dev)
+        self.energy = torch.empty((self.n_chains, self.H, self.W), dtype=self.state_dtype, device=self.dev)
         loss0 = torch.zeros(self.n_chains, dtype=torch.float64, device=self.dev)
         with torch.cuda.device(self.dev):
             self._check(self.lib.gsm_init_loss(self.h, _ptr(self.beds), _ptr(self.energy), _ptr(self.loss_sum), _ptr(loss0),

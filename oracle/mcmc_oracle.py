@@ -243,9 +243,12 @@ def mc_residual(bed, surf, velx, vely, dhdt, smb, resolution):
     return dx + dy + dhdt - smb
 
 
-def gaussian_loss(mc_res, mc_region_mask, sigma_mc):
+def gaussian_loss(mc_res, mc_region_mask, sigma_mc, state_f32=False):
     """(total, loss_mc, loss_data) with loss_data == 0 (MCMC.py:1021-1044)."""
-    loss_mc = np.nansum(np.square(mc_res[mc_region_mask == 1])) / (2 * sigma_mc ** 2)
+    sq = np.square(mc_res[mc_region_mask == 1])
+    if state_f32:
+        sq = sq.astype(np.float32).astype(np.float64)
+    loss_mc = np.nansum(sq) / (2 * sigma_mc ** 2)
     return loss_mc + 0, loss_mc, 0
 
 
@@ -269,6 +272,9 @@ class ChainConfig:
     sigma_mc: float
     update_in_region: bool = True
     block_type: str = "CRF_weight"
+    # build-defined mixed-precision mode (BASELINE configs[4]; not in the reference, whose torch class is all-fp32,
+    # MCMC_gpu.py:261): bed and per-cell squared residuals are stored as float32, arithmetic stays float64
+    state_f32: bool = False
 
 
 @dataclass
@@ -309,6 +315,8 @@ def mh_step(cfg: ChainConfig, bed_c, mc_res, loss_prev, f, row, col, u):
     bed_next[r0:r1, c0:c1] = bed_next[r0:r1, c0:c1] + pert
     upd_mask = cfg.region_mask if cfg.update_in_region else cfg.grounded_ice_mask
     bed_next = np.where(upd_mask, bed_next, bed_c)
+    if cfg.state_f32:
+        bed_next = bed_next.astype(np.float32).astype(np.float64)
 
     hr0, hr1 = max(0, r0 - 1), min(H, r1 + 1)
     hc0, hc1 = max(0, c0 - 1), min(W, c1 + 1)
@@ -317,7 +325,7 @@ def mh_step(cfg: ChainConfig, bed_c, mc_res, loss_prev, f, row, col, u):
                       cfg.dhdt[hr0:hr1, hc0:hc1], cfg.smb[hr0:hr1, hc0:hc1], cfg.resolution)
     cand = mc_res.copy()
     cand[r0:r1, c0:c1] = loc[r0 - hr0: r0 - hr0 + (r1 - r0), c0 - hc0: c0 - hc0 + (c1 - c0)]
-    loss_next = gaussian_loss(cand, cfg.mc_region_mask, cfg.sigma_mc)[0]
+    loss_next = gaussian_loss(cand, cfg.mc_region_mask, cfg.sigma_mc, cfg.state_f32)[0]
 
     thick = cfg.surf[r0:r1, c0:c1] - bed_next[r0:r1, c0:c1]
     if np.sum((thick <= 0)[upd_mask[r0:r1, c0:c1] == 1]) > 0:
@@ -345,9 +353,9 @@ def run_chain(cfg: ChainConfig, initial_bed, n_iter, rf: OracleRandField, rng: n
     bed_cache = None if only_save_last_bed else np.zeros((n_iter, H, W))
     trace = StepTrace() if record else None
 
-    bed_c = initial_bed
+    bed_c = initial_bed.astype(np.float32).astype(np.float64) if cfg.state_f32 else initial_bed
     mc_res = mc_residual(bed_c, cfg.surf, cfg.velx, cfg.vely, cfg.dhdt, cfg.smb, cfg.resolution)
-    loss_prev = gaussian_loss(mc_res, cfg.mc_region_mask, cfg.sigma_mc)[0]
+    loss_prev = gaussian_loss(mc_res, cfg.mc_region_mask, cfg.sigma_mc, cfg.state_f32)[0]
     loss_cache[0] = loss_mc_cache[0] = loss_prev
     if bed_cache is not None:
         bed_cache[0] = bed_c

@@ -4,12 +4,12 @@ import numpy as np
 import mcmc_oracle as orc
 
 
-def make_engine(H, n_chains, block_type="CRF_weight", update_in_region=True, rf_params=None, W=None):
+def make_engine(H, n_chains, block_type="CRF_weight", update_in_region=True, rf_params=None, W=None, state_dtype="f64"):
     from mcmc_gpu_amd.engine import GsmEngine
     prob, cfg, pairs, masks, rfp = orc.standard_setup(H, W, block_type=block_type,
                                                       update_in_region=update_in_region, rf_params=rf_params)
     Hh, Ww = prob["bed"].shape
-    eng = GsmEngine(Hh, Ww, n_chains)
+    eng = GsmEngine(Hh, Ww, n_chains, state_dtype=state_dtype)
     upd = cfg.region_mask if update_in_region else cfg.grounded_ice_mask
     eng.set_static(cfg.surf, cfg.velx, cfg.vely, cfg.dhdt, cfg.smb,
                    cfg.crf_data_weight if block_type == "CRF_weight" else None,
@@ -19,7 +19,8 @@ def make_engine(H, n_chains, block_type="CRF_weight", update_in_region=True, rf_
     return eng, prob, cfg, pairs, masks, rfp
 
 
-def oracle_chains(prob, cfg, pairs, masks, rfp, n_chains, n_iter, seed0=7):
+def oracle_chains(prob, cfg, pairs, masks, rfp, n_chains, n_iter, seed0=7, state_f32=False):
+    cfg.state_f32 = state_f32
     outs = []
     for c in range(n_chains):
         rf = orc.OracleRandField(rfp, seed0 + c, pairs, masks, prob["resolution"])

@@ -150,3 +150,25 @@ def test_bad_device_data_is_reported():
     with pytest.raises(ValueError):
         eng.run_replay(np.array([[0]]), np.array([[[64, 3]]]), np.array([[0.5]]), fields)
     eng.close()
+
+
+def test_f32_state_mode_matches_its_oracle_and_tracks_fp64():
+    """dtype 1: bed and energies stored as float32, arithmetic in fp64 (BASELINE configs[4]).  Bit-exact accept
+    masks and beds against the oracle's emulation of the same rounding; against the fp64 chain the accept masks agree
+    and the loss differs by float32 storage noise only (the reference's own all-fp32 twin: <= 2.8e-7)."""
+    eng, prob, cfg, pairs, masks, rfp = make_engine(64, 3, state_dtype="f32")
+    outs32 = oracle_chains(prob, cfg, pairs, masks, rfp, 3, 300, state_f32=True)
+    loss0 = eng.set_state(np.stack([orc.chain_initial_bed(prob, c) for c in range(3)]))
+    loss, acc = eng.run_replay(*replay_inputs(eng, outs32))
+    assert eng.beds.dtype.itemsize == 4 and eng.energy.dtype.itemsize == 4
+    for c, o in enumerate(outs32):
+        assert abs(loss0[c] - o[3][0]) <= 1e-10 * abs(o[3][0])
+        assert np.array_equal(acc[c], o[4][1:].astype(np.uint8))
+        np.testing.assert_allclose(loss[c], o[3][1:], rtol=1e-10)
+        assert np.array_equal(eng.beds[c].cpu().numpy().astype(np.float64), o[0])
+    outs64 = oracle_chains(prob, cfg, pairs, masks, rfp, 3, 300, state_f32=False)
+    for c in range(3):
+        assert (outs64[c][4] != outs32[c][4]).sum() <= 1
+        np.testing.assert_allclose(outs32[c][3][:50], outs64[c][3][:50], rtol=1e-6)
+    cfg.state_f32 = False
+    eng.close()
