@@ -219,46 +219,49 @@ extern "C" int gsm_set_blocks(gsm_handle h, int32_t n_sizes, const int32_t* bh, 
     if (h->d_masks) { hipFree(h->d_masks); h->d_masks = nullptr; }
     if (h->d_mask_off) { hipFree(h->d_mask_off); h->d_mask_off = nullptr; }
   }
-  // DFT operand tables of the proposal kernel, one set per distinct block height / width (zero padded to the
-  // MFMA tile grid; dimension formulas mirror propose_kernel):
-  //   height n: FC[ky][y] = cos(2 pi ky y / n), FS = sin(...), each [K1 = ceil4(n)][N1 = ceil16(n)]
-  //   width  n: G[k][x]        = c_k cos(2 pi k x / n)      k <  ncol = n/2+1   (c_k = 1 for k in {0, n/2}, else 2)
-  //             G[Kc + k][x]   = -c_k sin(2 pi k x / n)                          Kc = ceil4(ncol), [2 Kc][N2 = ceil16(n)]
+  // DFT operand tables of the proposal kernel, one set per distinct block height / width, folded to indices <= n/2
+  // and zero padded to the MFMA tile grid (dimension formulas mirror propose_kernel):
+  //   height n: FC[ky][y] = cos(2 pi ky y / n), FS = sin(...), ky, y <= n/2, each [KR = ceil4(n/2+1)][NR = ceil16(n/2+1)]
+  //   width  n: GC[k][x]  = c_k cos(2 pi k x / n), GS = -c_k sin(...), k, x <= n/2 (c_k = 1 for k in {0, n/2}, else 2),
+  //             each [Kc = ceil4(n/2+1)][M1 = ceil16(n/2+1)]
   const int max_len = std::max(max_bh, max_bw);
   std::vector<int32_t> fy_off(max_len + 1, -1), g_off(max_len + 1, -1);
   std::vector<double> tb;
-  int k1max = 0, n1max = 0, m1max = 0, k2max = 0, tiles_max = 0;
+  int krmax = 0, n1max = 0, m1max = 0, kcmax = 0, tiles_max = 0;
+  h->prop_tiles1 = 0;
   for (int i = 0; i < n_sizes; ++i) {
     const int n = bh[i];
-    const int K1 = (n + 3) & ~3, N1 = (n + 15) & ~15;
-    k1max = std::max(k1max, K1); n1max = std::max(n1max, N1);
+    const int nrow = n / 2 + 1;
+    const int KR = (nrow + 3) & ~3, NR = (nrow + 15) & ~15, N1 = (n + 15) & ~15;
+    krmax = std::max(krmax, KR); n1max = std::max(n1max, N1);
     if (fy_off[n] < 0) {
       fy_off[n] = (int32_t)tb.size();
-      tb.resize(tb.size() + (size_t)2 * K1 * N1, 0.0);
+      tb.resize(tb.size() + (size_t)2 * KR * NR, 0.0);
       double* FC = tb.data() + fy_off[n];
-      double* FS = FC + (size_t)K1 * N1;
-      for (int ky = 0; ky < n; ++ky)
-        for (int y = 0; y < n; ++y) {
+      double* FS = FC + (size_t)KR * NR;
+      for (int ky = 0; ky < nrow; ++ky)
+        for (int y = 0; y < nrow; ++y) {
           const double ang = 2.0 * M_PI * (double)(((int64_t)ky * y) % n) / (double)n;
-          FC[ky * N1 + y] = cos(ang);
-          FS[ky * N1 + y] = sin(ang);
+          FC[ky * NR + y] = cos(ang);
+          FS[ky * NR + y] = sin(ang);
         }
     }
     const int w = bw[i];
-    const int ncol = w / 2 + 1, Kc = (ncol + 3) & ~3, N2 = (w + 15) & ~15, M1 = (ncol + 15) & ~15;
-    m1max = std::max(m1max, M1); k2max = std::max(k2max, 2 * Kc);
-    tiles_max = std::max(tiles_max, (N1 / 16) * (N2 / 16));
-    h->prop_tiles1 = std::max(h->prop_tiles1, (M1 / 16) * (N1 / 16));
+    const int ncol = w / 2 + 1, Kc = (ncol + 3) & ~3, M1 = (ncol + 15) & ~15;
+    m1max = std::max(m1max, M1); kcmax = std::max(kcmax, Kc);
+    tiles_max = std::max(tiles_max, (N1 / 16) * (M1 / 16));
+    h->prop_tiles1 = std::max(h->prop_tiles1, (M1 / 16) * (NR / 16));
     if (g_off[w] < 0) {
       g_off[w] = (int32_t)tb.size();
-      tb.resize(tb.size() + (size_t)2 * Kc * N2, 0.0);
-      double* G = tb.data() + g_off[w];
+      tb.resize(tb.size() + (size_t)2 * Kc * M1, 0.0);
+      double* GC = tb.data() + g_off[w];
+      double* GS = GC + (size_t)Kc * M1;
       for (int k = 0; k < ncol; ++k) {
         const double ck = (k == 0 || k == w / 2) ? 1.0 : 2.0;
-        for (int x = 0; x < w; ++x) {
+        for (int x = 0; x < ncol; ++x) {
           const double ang = 2.0 * M_PI * (double)(((int64_t)k * x) % w) / (double)w;
-          G[k * N2 + x] = ck * cos(ang);
-          G[(Kc + k) * N2 + x] = -ck * sin(ang);
+          GC[k * M1 + x] = ck * cos(ang);
+          GS[k * M1 + x] = -ck * sin(ang);
         }
       }
     }
@@ -266,8 +269,8 @@ extern "C" int gsm_set_blocks(gsm_handle h, int32_t n_sizes, const int32_t* bh, 
   auto stride16mod32 = [](int v) { int s = v; while ((s & 31) != 16) ++s; return s; };
   h->lds_sx = stride16mod32(m1max);
   h->lds_st = stride16mod32(n1max);
-  h->lds_x_half = k1max * h->lds_sx;
-  h->lds_tt = k2max * h->lds_st;
+  h->lds_x_half = krmax * h->lds_sx;          // one of the four folded coefficient planes
+  h->lds_tt = 2 * kcmax * h->lds_st;
   h->prop_tiles = tiles_max;
   HIPCHK(h, dup_device(&h->d_tables, tb.data(), tb.size(), st));
   HIPCHK(h, dup_device(&h->d_fy_off, fy_off.data(), fy_off.size(), st));
@@ -364,7 +367,7 @@ static int check_propose_ready(gsm_handle h, const gsm_rf_params* rf, const char
   if (!(rf->resolution > 0.0)) return fail(h, GSM_E_ARG, std::string(who) + ": rf.resolution must be > 0");
   if (rf->model == GSM_MODEL_MATERN && !(rf->smoothness > 0.0))
     return fail(h, GSM_E_ARG, std::string(who) + ": Matern needs smoothness > 0");
-  const size_t lds = ((size_t)std::max(2 * h->lds_x_half, h->lds_tt) + 64) * 8;
+  const size_t lds = ((size_t)std::max(4 * h->lds_x_half, h->lds_tt) + 64) * 8;
   if (lds > 160 * 1024 || h->prop_tiles > propose_max_tiles_per_wave() * propose_waves() ||
       h->prop_tiles1 > propose_max_tiles1_per_wave() * propose_waves())
     return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": block too large for the proposal kernel (LDS / accumulator tiles)");
@@ -406,7 +409,7 @@ static ProposeArgs make_propose(gsm_handle h, const gsm_rf_params* rf, int n_ste
   p.centres = h->d_centres; p.n_centres = h->n_centres;
   p.tables = h->d_tables; p.fy_off = h->d_fy_off; p.g_off = h->d_g_off;
   p.lds_sx = h->lds_sx; p.lds_st = h->lds_st; p.lds_x_half = h->lds_x_half; p.lds_tt = h->lds_tt;
-  p.lds_main = std::max(2 * h->lds_x_half, h->lds_tt);
+  p.lds_main = std::max(4 * h->lds_x_half, h->lds_tt);
   return p;
 }
 

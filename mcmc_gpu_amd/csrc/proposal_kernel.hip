@@ -15,11 +15,12 @@
 // runs a complex-to-real inverse DFT: columns first (complex, bw/2+1 of them), then rows (real output).
 //
 // The two DFT stages are dense fp64 matrix products on the matrix cores (v_mfma_f64_16x16x4_f64):
-//   stage 1   T^T[kx][y]  = sum_ky X[ky][kx] * exp(+2 pi i ky y / bh)      A = X^T (LDS), B = cos/sin table (L2)
-//   stage 2   field[y][x] = sum_k2 T^T[k2][y] * G[k2][x]                    A = T^T (LDS), B = G table (L2)
-// with G rows = c_k cos(2 pi k x / bw) for the real rows and -c_k sin(...) for the imaginary rows (c_k = 1 for
-// k in {0, bw/2}, else 2: the folded Hermitian half).  The field never touches LDS: it stays in the MFMA
-// accumulators through the standardisation and goes straight to HBM.
+//   stage 1   T^T[kx][y]  = sum_ky X[ky][kx] * exp(+2 pi i ky y / bh)      A = folded X^T (LDS), B = cos/sin table (L2)
+//   stage 2   field[y][x] = sum_k (Tr^T[k][y] Gc[k][x] + Ti^T[k][y] Gs[k][x])  A = T^T (LDS), B = G tables (L2)
+// with Gc = c_k cos(2 pi k x / bw), Gs = -c_k sin(...) (c_k = 1 for k in {0, bw/2}, else 2: the Hermitian half), both
+// folded by the even/odd symmetry of cos/sin so that only indices <= n/2 enter the products (4x / 2x fewer flops than
+// the dense DFT; see propose_kernel).  The field never touches LDS: it stays in the MFMA accumulators through the
+// standardisation and goes straight to HBM.
 //
 // MFMA operand maps used here (16x16x4 f64): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
 // C/D reg q: row = (lane >> 4) + 4 q, col = lane & 15.
@@ -34,7 +35,7 @@ namespace gsm {
 constexpr int kPBlock = 512;
 constexpr int kPWaves = kPBlock / 64;
 constexpr int kMaxT1 = 2;   // stage-1 output tiles per wave
-constexpr int kMaxT2 = 4;   // stage-2 output tiles per wave
+constexpr int kMaxT2 = 2;   // stage-2 output tiles per wave
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t pmagic(uint32_t d) { return (uint32_t)(0xFFFFFFFFu / d) + 1u; }
@@ -135,12 +136,18 @@ __device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const Pro
   return sqrt(Sp);
 }
 
+// DFT folding used below (n even, h = n/2).  With P[k] = X[k] + X[n-k], M[k] = X[k] - X[n-k] (0 < k < h; P = X, M = 0
+// for k in {0, h}):   sum_k X[k] e^{+i t k y} = U[y] + i V[y],  U = sum_{k<=h} P[k] cos(t k y),  V = sum_{k<h} M[k] sin(t k y)
+// and the mirrored output is  U[y] - i V[y]  at n - y.  Only k, y in [0, h] enter the products: 4x fewer flops than the
+// dense complex DFT.  The real (c2r) stage folds the same way in x: field[y][x] = E + O, field[y][bw - x] = E - O.
 __global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a) {
   extern __shared__ double plds[];
   const int SX = a.lds_sx, ST = a.lds_st;
-  double* Xr = plds;                       // [K1max][SX]
-  double* Xi = Xr + a.lds_x_half;          // [K1max][SX]
-  double* TT = plds;                       // [K2max][ST]  -- overlays X once stage 1 has consumed it
+  double* Pr = plds;                       // 4 planes [KRmax][SX]: P re, P im, M re, M im
+  double* Pi = Pr + a.lds_x_half;
+  double* Mr = Pi + a.lds_x_half;
+  double* Mi = Mr + a.lds_x_half;
+  double* TT = plds;                       // [2 Kc][ST]  -- overlays the planes once stage 1 has consumed them
   double* red = plds + a.lds_main;         // [kPWaves]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -152,30 +159,31 @@ __global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a
   const PropScalars sc = a.scalars[rec];
   const int si = sc.si;
   const int bh = a.B.bh[si], bw = a.B.bw[si];
-  const int ncol = bw / 2 + 1;
+  const int hh = bh / 2, hw = bw / 2;
+  const int ncol = hw + 1, nrow = hh + 1;
 
   // padded GEMM dimensions (host builds the tables with the same formulas)
-  const int K1 = (bh + 3) & ~3;            // stage-1 K  (ky)
-  const int N1 = (bh + 15) & ~15;          // stage-1 N  (y)   = stage-2 M
-  const int M1 = (ncol + 15) & ~15;        // stage-1 M  (kx)
-  const int Kc = (ncol + 3) & ~3;          // rows per (re | im) half of T^T
-  const int K2 = 2 * Kc;                   // stage-2 K
-  const int N2 = (bw + 15) & ~15;          // stage-2 N  (x)
+  const int KR = (nrow + 3) & ~3;          // stage-1 K  (ky <= hh)
+  const int NR = (nrow + 15) & ~15;        // stage-1 N  (y  <= hh)
+  const int M1 = (ncol + 15) & ~15;        // stage-1 M  (kx)  = stage-2 N (x <= hw)
+  const int Kc = (ncol + 3) & ~3;          // stage-2 K per half (re | im rows of T^T)
+  const int N1 = (bh + 15) & ~15;          // stage-2 M  (y)
 
-  // ---- Hermitian half-plane coefficients X[ky][kx] -> LDS ---------------------------------------
-  // zero the padding (rows bh..K1, columns ncol..M1), then one work item per (ky <= bh/2, kx): the spectral
-  // amplitude is shared by rows ky and bh-ky, and on the two self-conjugate columns those rows are a
-  // conjugate pair built from the same two draws.
+  // ---- folded Hermitian half-plane coefficients -> LDS -------------------------------------------
+  // one work item per (ky <= hh, kx): rows ky and bh-ky share the spectral amplitude, and on the two self-conjugate
+  // columns they are a conjugate pair built from the same two draws.
   {
-    const int npad = K1 * M1;
+    const int npad = KR * M1;
     const uint32_t m_m1 = pmagic((uint32_t)M1);
     for (int i = tid; i < npad; i += kPBlock) {
       const int ky = (int)__umulhi((uint32_t)i, m_m1);
       const int kx = i - ky * M1;
-      if (ky >= bh || kx >= ncol) { Xr[ky * SX + kx] = 0.0; Xi[ky * SX + kx] = 0.0; }
+      if (ky >= nrow || kx >= ncol) {
+        const int o = ky * SX + kx;
+        Pr[o] = 0.0; Pi[o] = 0.0; Mr[o] = 0.0; Mi[o] = 0.0;
+      }
     }
-    const int hh = bh / 2;
-    const int nitem = (hh + 1) * ncol;
+    const int nitem = nrow * ncol;
     const uint32_t m_nc = pmagic((uint32_t)ncol);
     for (int i = tid; i < nitem; i += kPBlock) {
       const int ky = (int)__umulhi((uint32_t)i, m_nc);
@@ -189,58 +197,54 @@ __global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a
         normals2(seed, step, kStreamSpectrum, (uint32_t)(ky * ncol + kx), g1, g2);
         if (paired) normals2(seed, step, kStreamSpectrum, (uint32_t)(kyc * ncol + kx), h1, h2);
       }
-      if (kx > 0 && kx < bw / 2) {
-        Xr[ky * SX + kx] = amp * (g1 * M_SQRT1_2);
-        Xi[ky * SX + kx] = amp * (g2 * M_SQRT1_2);
-        if (paired) {
-          Xr[kyc * SX + kx] = amp * (h1 * M_SQRT1_2);
-          Xi[kyc * SX + kx] = amp * (h2 * M_SQRT1_2);
-        }
+      double ar, ai, br = 0.0, bi = 0.0;   // X[ky], X[bh - ky]
+      if (kx > 0 && kx < hw) {
+        ar = amp * (g1 * M_SQRT1_2); ai = amp * (g2 * M_SQRT1_2);
+        if (paired) { br = amp * (h1 * M_SQRT1_2); bi = amp * (h2 * M_SQRT1_2); }
       } else if (paired) {
-        Xr[ky * SX + kx] = amp * (0.5 * (g1 + h1));
-        Xi[ky * SX + kx] = amp * (0.5 * (g2 - h2));
-        Xr[kyc * SX + kx] = amp * (0.5 * (h1 + g1));
-        Xi[kyc * SX + kx] = amp * (0.5 * (h2 - g2));
+        ar = amp * (0.5 * (g1 + h1)); ai = amp * (0.5 * (g2 - h2));
+        br = amp * (0.5 * (h1 + g1)); bi = amp * (0.5 * (h2 - g2));
       } else {
-        Xr[ky * SX + kx] = amp * (0.5 * (g1 + g1));
-        Xi[ky * SX + kx] = amp * (0.5 * (g2 - g2));
+        ar = amp * (0.5 * (g1 + g1)); ai = amp * (0.5 * (g2 - g2));
       }
+      const int o = ky * SX + kx;
+      Pr[o] = ar + br; Pi[o] = ai + bi;
+      Mr[o] = paired ? ar - br : 0.0;
+      Mi[o] = paired ? ai - bi : 0.0;
     }
   }
   __syncthreads();
 
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  // ---- stage 1 (MFMA): T^T[kx][y] = sum_ky X[ky][kx] (cos + i sin)(2 pi ky y / bh) ----------------
-  // results wait in registers until every wave has finished reading X, then overwrite it as T^T
-  v4f64 t1r[kMaxT1], t1i[kMaxT1];
-  const int n_mt = M1 >> 4, n_nt = N1 >> 4;
+  // ---- stage 1 (MFMA): U = P^T C, V = M^T S on ky, y in [0, hh] -----------------------------------
+  // results wait in registers until every wave has finished reading the planes, then overwrite them as T^T
+  v4f64 ur[kMaxT1], ui[kMaxT1], vr[kMaxT1], vi[kMaxT1];
+  const int n_mt = M1 >> 4, n_nt = NR >> 4;
   const int n_t1 = n_mt * n_nt;
   {
-    const double* __restrict__ FC = a.tables + a.fy_off[bh];   // [K1][N1]
-    const double* __restrict__ FS = FC + K1 * N1;
+    const double* __restrict__ FC = a.tables + a.fy_off[bh];   // [KR][NR]
+    const double* __restrict__ FS = FC + KR * NR;
 #pragma unroll
     for (int j = 0; j < kMaxT1; ++j) {
-      v4f64 accr = {0.0, 0.0, 0.0, 0.0}, acci = {0.0, 0.0, 0.0, 0.0};
+      v4f64 aur = {0.0, 0.0, 0.0, 0.0}, aui = aur, avr = aur, avi = aur;
       const int t = wave + j * kPWaves;
       if (t < n_t1 && !(a.dbg & 2)) {
         const int mt = t % n_mt, nt = t / n_mt;
-        const double* xr_p = Xr + l4 * SX + 16 * mt + l15;
-        const double* xi_p = Xi + l4 * SX + 16 * mt + l15;
-        const double* fc_p = FC + l4 * N1 + 16 * nt + l15;
-        const double* fs_p = FS + l4 * N1 + 16 * nt + l15;
-#pragma unroll 4
-        for (int k0 = 0; k0 < K1; k0 += 4) {
-          const double ar = xr_p[k0 * SX], ai = xi_p[k0 * SX];
-          const double bc = fc_p[k0 * N1], bs = fs_p[k0 * N1];
-          accr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bc, accr, 0, 0, 0);
-          accr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bs, accr, 0, 0, 0);
-          acci = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bs, acci, 0, 0, 0);
-          acci = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bc, acci, 0, 0, 0);
+        const int ao = l4 * SX + 16 * mt + l15;
+        const double* fc_p = FC + l4 * NR + 16 * nt + l15;
+        const double* fs_p = FS + l4 * NR + 16 * nt + l15;
+#pragma unroll 2
+        for (int k0 = 0; k0 < KR; k0 += 4) {
+          const double bc = fc_p[k0 * NR], bs = fs_p[k0 * NR];
+          const int o = ao + k0 * SX;
+          aur = __builtin_amdgcn_mfma_f64_16x16x4f64(Pr[o], bc, aur, 0, 0, 0);
+          aui = __builtin_amdgcn_mfma_f64_16x16x4f64(Pi[o], bc, aui, 0, 0, 0);
+          avr = __builtin_amdgcn_mfma_f64_16x16x4f64(Mr[o], bs, avr, 0, 0, 0);
+          avi = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[o], bs, avi, 0, 0, 0);
         }
       }
-      t1r[j] = accr;
-      t1i[j] = acci;
+      ur[j] = aur; ui[j] = aui; vr[j] = avr; vi[j] = avi;
     }
   }
   __syncthreads();
@@ -250,42 +254,52 @@ __global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a
     if (t < n_t1) {
       const int mt = t % n_mt, nt = t / n_mt;
       const int y = 16 * nt + l15;
+      if (y <= hh) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int kx = 16 * mt + l4 + 4 * q;
-        if (kx < Kc) {
-          TT[kx * ST + y] = t1r[j][q];
-          TT[(Kc + kx) * ST + y] = t1i[j][q];
+        for (int q = 0; q < 4; ++q) {
+          const int kx = 16 * mt + l4 + 4 * q;
+          if (kx < Kc) {
+            TT[kx * ST + y] = ur[j][q] - vi[j][q];
+            TT[(Kc + kx) * ST + y] = ui[j][q] + vr[j][q];
+            if (y > 0 && y < hh) {
+              TT[kx * ST + (bh - y)] = ur[j][q] + vi[j][q];
+              TT[(Kc + kx) * ST + (bh - y)] = ui[j][q] - vr[j][q];
+            }
+          }
         }
       }
     }
   }
   __syncthreads();
 
-  // ---- stage 2 (MFMA): field[y][x] = sum_k2 T^T[k2][y] G[k2][x]; result stays in registers -------
-  v4f64 fld[kMaxT2];
-  const int n_mt2 = N1 >> 4, n_nt2 = N2 >> 4;
+  // ---- stage 2 (MFMA): E = Tr^T Gc, O = Ti^T Gs on x in [0, hw]; results stay in registers -----------
+  v4f64 fe[kMaxT2], fo[kMaxT2];
+  const int n_mt2 = N1 >> 4, n_nt2 = M1 >> 4;
   const int n_t2 = n_mt2 * n_nt2;
   {
-    const double* __restrict__ G = a.tables + a.g_off[bw];     // [K2][N2]
+    const double* __restrict__ GC = a.tables + a.g_off[bw];    // [Kc][M1]
+    const double* __restrict__ GS = GC + Kc * M1;
 #pragma unroll
     for (int j = 0; j < kMaxT2; ++j) {
-      fld[j] = v4f64{0.0, 0.0, 0.0, 0.0};
+      v4f64 ae = {0.0, 0.0, 0.0, 0.0}, ao = ae;
       const int t = wave + j * kPWaves;
       if (t < n_t2 && !(a.dbg & 4)) {
         const int mt = t % n_mt2, nt = t / n_mt2;
         const double* a_p = TT + l4 * ST + 16 * mt + l15;
-        const double* b_p = G + l4 * N2 + 16 * nt + l15;
-        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-        for (int k0 = 0; k0 < K2; k0 += 4)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p[k0 * ST], b_p[k0 * N2], acc, 0, 0, 0);
-        fld[j] = acc;
+        const double* gc_p = GC + l4 * M1 + 16 * nt + l15;
+        const double* gs_p = GS + l4 * M1 + 16 * nt + l15;
+#pragma unroll 2
+        for (int k0 = 0; k0 < Kc; k0 += 4) {
+          ae = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p[k0 * ST], gc_p[k0 * M1], ae, 0, 0, 0);
+          ao = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p[(Kc + k0) * ST], gs_p[k0 * M1], ao, 0, 0, 0);
+        }
       }
+      fe[j] = ae; fo[j] = ao;
     }
   }
 
   // ---- standardise (MCMC.py:248) on the register-resident field ---------------------------------
+  // lane holds, per (tile j, reg q): v1 = field[y][x] = E + O and, for 0 < x < hw, v2 = field[y][bw - x] = E - O
   const int ncell = bh * bw;
   const double inv_n = 1.0 / (double)ncell;
   double part = 0.0;
@@ -297,9 +311,13 @@ __global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int y = 16 * mt + l4 + 4 * q;
-      const bool ok = (t < n_t2) && (y < bh) && (x < bw);
-      fld[j][q] = ok ? fld[j][q] * inv_n : 0.0;
-      part += fld[j][q];
+      const bool ok = (t < n_t2) && (y < bh) && (x <= hw);
+      const bool two = ok && (x > 0) && (x < hw);
+      const double e = fe[j][q], o = fo[j][q];
+      const double v1 = ok ? (e + o) * inv_n : 0.0;
+      const double v2 = two ? (e - o) * inv_n : 0.0;
+      fe[j][q] = v1; fo[j][q] = v2;
+      part += v1 + v2;
     }
   }
   const double mean = block_sum(part, red, tid) * inv_n;
@@ -312,7 +330,9 @@ __global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int y = 16 * mt + l4 + 4 * q;
-      if ((t < n_t2) && (y < bh) && (x < bw)) { const double d = fld[j][q] - mean; part += d * d; }
+      const bool ok = (t < n_t2) && (y < bh) && (x <= hw);
+      if (ok) { const double d = fe[j][q] - mean; part += d * d; }
+      if (ok && x > 0 && x < hw) { const double d = fo[j][q] - mean; part += d * d; }
     }
   }
   const double sd = sqrt(block_sum(part, red, tid) * inv_n);
@@ -331,15 +351,19 @@ __global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int y = 16 * mt + l4 + 4 * q;
-      if ((t < n_t2) && (y < bh) && (x < bw)) {
-        const int o = y * bw + x;
-        double v = (fld[j][q] - mean) * gain;
-        if (with_nugget) {
-          double n1, n2;
-          normals2(seed, step, kStreamNugget, (uint32_t)(o >> 1), n1, n2);
-          v = v + ((o & 1) ? n2 : n1) * sq_nug;
+      if ((t < n_t2) && (y < bh) && (x <= hw)) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          if (half == 1 && !(x > 0 && x < hw)) continue;
+          const int o = y * bw + (half ? bw - x : x);
+          double v = ((half ? fo[j][q] : fe[j][q]) - mean) * gain;
+          if (with_nugget) {
+            double n1, n2;
+            normals2(seed, step, kStreamNugget, (uint32_t)(o >> 1), n1, n2);
+            v = v + ((o & 1) ? n2 : n1) * sq_nug;
+          }
+          out[o] = v * mask[o];
         }
-        out[o] = v * mask[o];
       }
     }
   }
