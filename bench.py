@@ -108,8 +108,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
-    ap.add_argument("--inner", type=int, default=32, help="Metropolis steps per chain in one bench step")
-    ap.add_argument("--batch", type=int, default=8, help="steps per kernel launch")
+    ap.add_argument("--inner", type=int, default=128, help="Metropolis steps per chain in one bench step")
+    ap.add_argument("--batch", type=int, default=32, help="steps per kernel launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--gather-beds", action="store_true", help="also all-gather the final beds (512 MiB per GPU at 256^2)")
@@ -223,7 +223,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if args.state == "f64" else "f64 arithmetic on f32 state", "data": "synthetic",
             "config": {"workload": f"largeScaleChain {H}x{H} grid, {n_local} chains/GPU, {'fp64' if args.state == 'f64' else 'fp32 state / fp64 arithmetic'}, Philox "
-                                   + ("spectral (Matern 0.9125) proposals, blocks 50-80, sigma_mc 5 (BASELINE configs[1])"
+                                   + ("spectral (Matern 0.9125) proposals, blocks 50-80, sigma_mc 5 "
+                                      + ("(BASELINE configs[1])" if args.state == "f64" else "(BASELINE configs[4], one GPU's shard)")
                                       if args.generator == "spectral" else
                                       f"precomputed-Cholesky (Matern 0.9125, {args.classes} range classes) proposals, "
                                       "blocks 50-80, sigma_mc 5 (BASELINE configs[3])"),

@@ -194,6 +194,7 @@ extern "C" int gsm_set_blocks(gsm_handle h, int32_t n_sizes, const int32_t* bh, 
                               const double* edge_masks_packed, const int64_t* mask_offsets, void* stream) {
   if (!h) return GSM_E_ARG;
   if (n_sizes < 1 || !bh || !bw) return fail(h, GSM_E_ARG, "gsm_set_blocks: empty block table");
+  if (n_sizes > 64) return fail(h, GSM_E_UNSUPPORTED, "gsm_set_blocks: at most 64 block sizes");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(h, hipSetDevice(h->device));
   int max_bh = 0, max_bw = 0, cap = 0;

@@ -148,12 +148,12 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
       const int lr = (int)__umulhi((uint32_t)i, m_tw);
       const int lc = i - lr * tw;
       const int g = (hr0 + lr) * W + hc0 + lc;
-      double v = (double)bed[g];
+      double v = (double)__builtin_nontemporal_load(&bed[g]);
       const int wr = lr - dr, wc = lc - dc;
       if ((unsigned)wr < (unsigned)wh && (unsigned)wc < (unsigned)ww) {
-        acc_old += (double)energy[g];
+        acc_old += (double)__builtin_nontemporal_load(&energy[g]);
         if (S.upd[g]) {
-          const double f = fld[(mr0 + wr) * bw + mc0 + wc];
+          const double f = __builtin_nontemporal_load(&fld[(mr0 + wr) * bw + mc0 + wc]);
           const double pert = S.weight ? f * S.weight[g] : f;
           v = v + pert;
           if (F32) v = (double)(float)v;
@@ -235,10 +235,10 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
           const int wc = i - wr * ww;
           const int r = r0 + wr, c = c0 + wc;
           const size_t g = (size_t)r * W + c;
-          energy[g] = (TS)e_new[k];
+          __builtin_nontemporal_store((TS)e_new[k], &energy[g]);
           if (S.upd[g]) {
-            bed[g] = (TS)tile[(r - hr0) * tw + (c - hc0)];
-            resamp[g] += 1u;
+            __builtin_nontemporal_store((TS)tile[(r - hr0) * tw + (c - hc0)], &bed[g]);
+            __builtin_nontemporal_store(__builtin_nontemporal_load(&resamp[g]) + 1u, &resamp[g]);
           }
         }
       }

@@ -24,7 +24,7 @@ def init_distributed(backend: str | None = None):
     rank, local_rank, world = dist_env()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("GSM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -45,11 +45,18 @@ def shard_bounds(n_chains: int, world: int, rank: int):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def _via_host(t: torch.Tensor) -> bool:
+    """gloo (CPU rehearsal of the multi-rank path) moves device tensors through the host; RCCL does not."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def all_gather_chains(local: torch.Tensor, n_chains: int) -> torch.Tensor:
     """All-gather per-chain rows (dim 0 = local chains, ragged across ranks allowed) into the full
     (n_chains, ...) tensor on every rank.  One collective; equal shards use all_gather_into_tensor."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
+    if _via_host(local):
+        return all_gather_chains(local.cpu(), n_chains).to(local.device)
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [shard_bounds(n_chains, world, r)[1] - shard_bounds(n_chains, world, r)[0] for r in range(world)]
     if local.shape[0] != sizes[rank]:
@@ -71,7 +78,12 @@ def all_reduce_mean_field(local_sum: torch.Tensor, n_chains: int) -> torch.Tenso
     """Posterior-mean field from per-rank sums over local chains: one all-reduce of an (H, W) tensor."""
     t = local_sum.clone()
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if _via_host(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t = h.to(t.device)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t / float(n_chains)
 
 
@@ -83,6 +95,6 @@ def barrier():
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -8,7 +8,7 @@ from mcmc_gpu_amd import synthetic
 from mcmc_gpu_amd.engine import _ptr
 import bench
 
-chains, steps = 1024, 8
+chains, steps = 1024, 32
 prob, ch, rf = synthetic.template(256)
 eng = ch._make_engine(rf, chains, 0)
 eng.set_state(synthetic.initial_beds(prob, chains))            # init_loss_kernel: read beds, write energy
