@@ -1,0 +1,122 @@
+"""-m gpu: BASELINE's full size (256x256 grid x 1024 chains, fp64, Philox mode) through size-independent
+properties -- the oracle cannot run this many chain-steps, the invariants below need no oracle:
+
+  P1  the carried energy array equals a from-scratch recompute of the final beds, BIT FOR BIT, for every chain
+      (the window-only residual update is exact: what the reference's carried mc_res also satisfies)
+  P2  the compensated carried sum equals the sum of the carried energy (<= 1e-12 rel), and the last loss_cache entry
+      equals the recomputed loss (<= 1e-10 rel, north_star's bound)
+  P3  resampled counts == number of accepted proposals covering each cell inside the update mask, exactly
+  P4  rejected steps repeat the previous loss exactly; cells outside the update mask never change
+  P5  the same launch split differently (batch 8 vs 32) gives identical results
+and non-square / edge-clipping geometry on a smaller ragged grid."""
+import numpy as np
+import pytest
+import torch
+
+import mcmc_oracle as orc
+from mcmc_gpu_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _windows_count(blocks, acc, H, W):
+    cnt = np.zeros((H, W), dtype=np.int64)
+    for (row, col, bh, bw), a in zip(blocks, acc):
+        if a:
+            r0, r1 = max(0, row - bh // 2), min(H, row + bh // 2)
+            c0, c1 = max(0, col - bw // 2), min(W, col + bw // 2)
+            cnt[r0:r1, c0:c1] += 1
+    return cnt
+
+
+def test_full_size_invariants():
+    H, n_chains, n_steps = 256, 1024, 96
+    prob, ch, rf = synthetic.template(H)
+    eng = ch._make_engine(rf, n_chains, 0)
+    beds0 = synthetic.initial_beds(prob, n_chains)
+    loss0 = eng.set_state(beds0)
+    seeds = list(range(500, 500 + n_chains))
+    loss, acc, blk = eng.run_philox(n_steps, 0, seeds, rf, batch=32)
+    beds = eng.beds.clone(); energy = eng.energy.clone(); res = eng.resampled.clone(); lsum = eng.loss_sum.clone()
+    assert 0.45 < acc.mean() < 0.65
+    # P1 / P2: recompute everything from the final beds
+    loss_re = eng.set_state(beds)
+    assert torch.equal(eng.energy, energy), "carried energy differs from a full recompute"
+    s_carried = (lsum[:, 0] + lsum[:, 1]).cpu().numpy()
+    s_energy = energy.sum(dim=(1, 2), dtype=torch.float64).cpu().numpy()
+    np.testing.assert_allclose(s_carried, s_energy, rtol=1e-12)
+    np.testing.assert_allclose(loss[:, -1], loss_re, rtol=1e-10)
+    # P4: rejected steps carry the loss; outside the region nothing moves
+    prev = np.concatenate([loss0[:, None], loss[:, :-1]], axis=1)
+    assert np.array_equal(loss[acc == 0], prev[acc == 0])
+    assert (loss[acc == 1] != prev[acc == 1]).mean() > 0.99
+    outside = torch.as_tensor(prob["region_mask"] == 0, device=beds.device)
+    assert torch.equal(beds[:, outside], torch.as_tensor(beds0, device=beds.device)[:, outside])
+    assert not torch.equal(beds, torch.as_tensor(beds0, device=beds.device))
+    # P3 on a sample of chains (host loop)
+    resh = res.cpu().numpy()
+    for c in (0, 1, 511, 1023):
+        exp = _windows_count(blk[c], acc[c], H, H) * (prob["region_mask"] == 1)
+        assert np.array_equal(resh[c], exp)
+    # P5
+    eng.set_state(beds0)
+    loss8, acc8, blk8 = eng.run_philox(n_steps, 0, seeds, rf, batch=8)
+    assert np.array_equal(acc8, acc) and np.array_equal(loss8, loss) and np.array_equal(blk8, blk)
+    assert torch.equal(eng.beds, beds) and torch.equal(eng.resampled, res)
+    eng.close()
+
+
+def test_ragged_grid_all_edges_clipped():
+    """48 x 80 grid (H != W), whole-map updates so that blocks hang over all four edges and the corners; replay
+    against the oracle on identical draws."""
+    from gpu_common import oracle_chains, replay_inputs
+    from mcmc_gpu_amd.engine import GsmEngine
+    prob, cfg, pairs, masks, rfp = orc.standard_setup(48, 80, block_type="CRF_weight", update_in_region=False)
+    eng = GsmEngine(48, 80, 2)
+    eng.set_static(cfg.surf, cfg.velx, cfg.vely, cfg.dhdt, cfg.smb, cfg.crf_data_weight, cfg.grounded_ice_mask,
+                   cfg.mc_region_mask, cfg.resolution, cfg.sigma_mc)
+    eng.set_blocks(pairs, masks)
+    outs = oracle_chains(prob, cfg, pairs, masks, rfp, 2, 400)
+    loss0 = eng.set_state(np.stack([orc.chain_initial_bed(prob, c) for c in range(2)]))
+    loss, acc = eng.run_replay(*replay_inputs(eng, outs))
+    clipped = set()
+    for c, o in enumerate(outs):
+        assert abs(loss0[c] - o[3][0]) <= 1e-10 * abs(o[3][0])
+        assert np.array_equal(acc[c], o[4][1:].astype(np.uint8))
+        np.testing.assert_allclose(loss[c], o[3][1:], rtol=1e-10)
+        assert np.array_equal(eng.beds[c].cpu().numpy(), o[0])
+        assert np.array_equal(eng.resampled[c].cpu().numpy().astype(float), o[5])
+        b = o[6][1:]
+        clipped |= {"top"} if (b[:, 0] - b[:, 2] / 2 < 0).any() else set()
+        clipped |= {"bottom"} if (b[:, 0] + b[:, 2] / 2 > 48).any() else set()
+        clipped |= {"left"} if (b[:, 1] - b[:, 3] / 2 < 0).any() else set()
+        clipped |= {"right"} if (b[:, 1] + b[:, 3] / 2 > 80).any() else set()
+    assert clipped == {"top", "bottom", "left", "right"}
+    eng.close()
+
+
+def test_block_as_large_as_the_grid_and_single_chain():
+    """One 16x16 block size on a 16x16 grid: every window is clipped to the whole map or less."""
+    from mcmc_gpu_amd.engine import GsmEngine
+    prob, cfg, _, _, rfp = orc.standard_setup(16, 16, block_min=16, block_max=16, update_in_region=False)
+    pairs = orc.block_pairs(16, 16, 16, 16, steps=1)
+    masks = orc.edge_masks(pairs, [2, 0, 6, 1], 49900.0, 500.0)
+    eng = GsmEngine(16, 16, 1)
+    eng.set_static(cfg.surf, cfg.velx, cfg.vely, cfg.dhdt, cfg.smb, cfg.crf_data_weight, cfg.grounded_ice_mask,
+                   cfg.mc_region_mask, cfg.resolution, cfg.sigma_mc)
+    eng.set_blocks(pairs, masks)
+    rf = orc.OracleRandField(rfp, 3, pairs, masks, 500.0)
+    out = orc.run_chain(cfg, prob["bed"].copy(), 120, rf, np.random.default_rng(3), record=True)
+    tr = out[7]
+    eng.set_state(prob["bed"][None])
+    loss, acc = eng.run_replay(np.array([tr.size_idx]), np.array([tr.centre]), np.array([tr.u]), eng.pack_fields([tr.fields]))
+    assert np.array_equal(acc[0], out[4][1:].astype(np.uint8))
+    np.testing.assert_allclose(loss[0], out[3][1:], rtol=1e-10)
+    assert np.array_equal(eng.beds[0].cpu().numpy(), out[0])
+    # a block larger than the grid is refused, like odd sizes
+    from mcmc_gpu_amd._lib import GsmError
+    with pytest.raises(GsmError):
+        eng.set_blocks(np.array([[18], [16]]), None)
+    with pytest.raises(GsmError):
+        eng.set_blocks(np.array([[7], [8]]), None)
+    eng.close()
