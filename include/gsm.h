@@ -180,6 +180,14 @@ int gsm_cov_assemble(gsm_handle h, int32_t bh, int32_t bw, double resolution, co
  * The reference has no such generator (README.md:21-23 lists it as future work); this is north_star's. */
 int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* const* factors, void* stream);
 
+/* Setup-time distance transform: dist[i] = Euclidean distance from cell i (coordinates xx[i], yy[i]) to the nearest
+ * cell with mask[i] != 0, all [dev, H*W].  Exact (brute force over the masked cells, same dx*dx + dy*dy, sqrt
+ * arithmetic as the KD-tree query).  Synchronises the stream.
+ * Replaces: Utilities.min_dist_from_mask (Utilities.py:21-24), used by RandField.get_crf_weight /
+ * chain_crf.set_crf_data_weight (MCMC.py:689-714, :1124-1134). */
+int gsm_min_dist_from_mask(gsm_handle h, const double* xx, const double* yy, const uint8_t* mask, double* dist,
+                           void* stream);
+
 /* Diagnostics: stream-copy n doubles src -> dst [dev] with the step kernel's access shape (8 bytes per lane,
  * coalesced).  A known byte count for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM). */
 int gsm_debug_stream_copy(const double* src, double* dst, int64_t n, void* stream);

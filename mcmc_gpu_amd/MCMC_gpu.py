@@ -33,8 +33,22 @@ __all__ = ["RandField", "chain_crf_gpu", "init_lsc_chain_by_instance", "initiate
            "spectral_synthesis_field", "run_many", "min_dist_from_mask"]
 
 
-def min_dist_from_mask(xx, yy, mask):
-    """Distance from every cell to the nearest True cell of `mask` (Utilities.py:21-24)."""
+def min_dist_from_mask(xx, yy, mask, device=True):
+    """Distance from every cell to the nearest True cell of `mask` (Utilities.py:21-24).  On a machine with a GPU the
+    exact brute-force HIP kernel is used (gsm_min_dist_from_mask); the host KD-tree (what the reference calls) is the
+    setup-time path elsewhere.  Both give the same values (test_min_dist_device_equals_kdtree)."""
+    if device:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                from .engine import GsmEngine
+                eng = GsmEngine(xx.shape[0], xx.shape[1], 1)
+                try:
+                    return eng.min_dist_from_mask(xx, yy, mask)
+                finally:
+                    eng.close()
+        except ImportError:
+            pass
     from scipy.spatial import cKDTree
     pts = np.array([xx[mask], yy[mask]]).T
     if pts.shape[0] == 0:

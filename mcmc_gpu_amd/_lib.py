@@ -116,6 +116,7 @@ def load() -> C.CDLL:
     lib.gsm_last_timing.argtypes = [vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(dbl), C.POINTER(i32)]
     lib.gsm_cov_assemble.argtypes = [vp, i32, i32, dbl, C.POINTER(Vario), vp, vp, i64, vp]
     lib.gsm_set_factors.argtypes = [vp, i32, C.POINTER(vp), vp]
+    lib.gsm_min_dist_from_mask.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.gsm_debug_stream_copy.argtypes = [vp, vp, i64, vp]
     lib.gsm_philox_selftest.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     for name in declared_symbols():

@@ -586,3 +586,26 @@ extern "C" int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* co
   h->n_classes = n_classes;
   return GSM_OK;
 }
+
+extern "C" int gsm_min_dist_from_mask(gsm_handle h, const double* xx, const double* yy, const uint8_t* mask,
+                                      double* dist, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!xx || !yy || !mask || !dist) return fail(h, GSM_E_ARG, "gsm_min_dist_from_mask: NULL pointer");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int n = h->H * h->W;
+  hipStream_t st = (hipStream_t)stream;
+  double2* pts = nullptr;
+  int* count = nullptr;
+  HIPCHK(h, hipMalloc(&pts, sizeof(double2) * (size_t)n));
+  HIPCHK(h, hipMalloc(&count, sizeof(int)));
+  HIPCHK(h, hipMemsetAsync(count, 0, sizeof(int), st));
+  hipError_t e = launch_min_dist(xx, yy, mask, n, pts, count, dist, st);
+  int m = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&m, count, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  hipFree(pts);
+  hipFree(count);
+  if (e != hipSuccess) return fail(h, GSM_E_HIP, std::string("gsm_min_dist_from_mask: ") + hipGetErrorString(e));
+  if (m == 0) return fail(h, GSM_E_ARG, "gsm_min_dist_from_mask: mask selects no cell");
+  return GSM_OK;
+}

@@ -127,6 +127,8 @@ int propose_max_tiles_per_wave();
 int propose_max_tiles1_per_wave();
 int propose_waves();
 size_t step_lds_bytes(int tile_cap);
+hipError_t launch_min_dist(const double* xx, const double* yy, const uint8_t* mask, int n, double2* pts, int* count,
+                           double* dist, hipStream_t st);
 hipError_t launch_stream_copy(const double* src, double* dst, int64_t n, hipStream_t st);
 
 }  // namespace gsm

@@ -383,6 +383,45 @@ hipError_t launch_pack_static(const StaticFields& S, double2* svx, double2* svy,
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Utilities.min_dist_from_mask (Utilities.py:21-24): distance of every cell to the nearest masked cell.
+// Exact brute force: min over masked points of (dx*dx + dy*dy), then sqrt -- the arithmetic of the KD-tree
+// query's final distance (no FMA: this file is built with -ffp-contract=off); points staged through LDS.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void compact_points_kernel(const double* xx, const double* yy, const uint8_t* mask,
+                                                                int n, double2* pts, int* count) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    if (mask[i]) pts[atomicAdd(count, 1)] = make_double2(xx[i], yy[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void min_dist_kernel(const double* __restrict__ xx, const double* __restrict__ yy,
+                                                          int n, const double2* __restrict__ pts,
+                                                          const int* __restrict__ count, double* __restrict__ dist) {
+  __shared__ double2 sp[kBlock];
+  const int m = *count;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const double x = (i < n) ? xx[i] : 0.0, y = (i < n) ? yy[i] : 0.0;
+  double best = INFINITY;
+  for (int p0 = 0; p0 < m; p0 += kBlock) {
+    if (p0 + (int)threadIdx.x < m) sp[threadIdx.x] = pts[p0 + threadIdx.x];
+    __syncthreads();
+    const int lim = min(kBlock, m - p0);
+    for (int j = 0; j < lim; ++j) {
+      const double dx = x - sp[j].x, dy = y - sp[j].y;
+      best = fmin(best, dx * dx + dy * dy);
+    }
+    __syncthreads();
+  }
+  if (i < n) dist[i] = sqrt(best);
+}
+
+hipError_t launch_min_dist(const double* xx, const double* yy, const uint8_t* mask, int n, double2* pts, int* count,
+                           double* dist, hipStream_t st) {
+  hipLaunchKernelGGL(compact_points_kernel, dim3(256), dim3(kBlock), 0, st, xx, yy, mask, n, pts, count);
+  hipLaunchKernelGGL(min_dist_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, xx, yy, n, pts, count, dist);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(kBlock) void stream_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) dst[i] = src[i];
 }

@@ -148,6 +148,17 @@ class GsmEngine:
                                                self._stream()))
         return loss0.cpu().numpy()
 
+    def min_dist_from_mask(self, xx, yy, mask):
+        """Distance of every cell to the nearest masked cell on the device (Utilities.py:21-24)."""
+        m = np.ascontiguousarray(np.asarray(mask) != 0).astype(np.uint8)
+        if m.shape != (self.H, self.W):
+            raise ValueError("mask has the wrong shape")
+        dx, dy, dm = self._f64(xx), self._f64(yy), torch.as_tensor(m).to(self.dev)
+        out = torch.empty((self.H, self.W), dtype=torch.float64, device=self.dev)
+        with torch.cuda.device(self.dev):
+            self._check(self.lib.gsm_min_dist_from_mask(self.h, _ptr(dx), _ptr(dy), _ptr(dm), _ptr(out), self._stream()))
+        return out.cpu().numpy()
+
     def residual(self, beds):
         b = beds.to(device=self.dev, dtype=torch.float64).contiguous() if isinstance(beds, torch.Tensor) else self._f64(beds)
         if tuple(b.shape) != (self.n_chains, self.H, self.W):

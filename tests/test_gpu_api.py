@@ -161,3 +161,20 @@ def test_topography_residual_on_device(golden_dir):
                                                          torch.tensor(g["dhdt"]), torch.tensor(g["smb"]),
                                                          float(g["resolution"]))
     assert t.is_cuda and np.array_equal(t.cpu().numpy(), g["residual"], equal_nan=True)
+
+
+def test_min_dist_device_equals_kdtree():
+    """gsm_min_dist_from_mask == scipy KD-tree distances (what Utilities.min_dist_from_mask returns), bit for bit,
+    and the crf weight built from it equals the oracle's (fixture F4 pins that to the reference)."""
+    prob, ch, rf = synthetic.template(64)
+    d_dev = MCMC_gpu.min_dist_from_mask(prob["xx"], prob["yy"], prob["data_mask"], device=True)
+    d_host = MCMC_gpu.min_dist_from_mask(prob["xx"], prob["yy"], prob["data_mask"], device=False)
+    assert np.array_equal(d_dev, d_host)
+    g = np.random.default_rng(0)
+    mask = g.random((96, 130)) < 0.01
+    xx, yy = np.meshgrid(np.arange(130) * 437.5 + 1e6, np.arange(96) * 437.5 - 2e5)
+    assert np.array_equal(MCMC_gpu.min_dist_from_mask(xx, yy, mask, True), MCMC_gpu.min_dist_from_mask(xx, yy, mask, False))
+    p2, cfg, *_ = orc.standard_setup(64)
+    assert np.array_equal(ch.crf_data_weight, cfg.crf_data_weight)     # template() ran the device path on this box
+    with pytest.raises(Exception):
+        MCMC_gpu.min_dist_from_mask(xx, yy, np.zeros_like(mask), True)
