@@ -178,3 +178,46 @@ def test_min_dist_device_equals_kdtree():
     assert np.array_equal(ch.crf_data_weight, cfg.crf_data_weight)     # template() ran the device path on this box
     with pytest.raises(Exception):
         MCMC_gpu.min_dist_from_mask(xx, yy, np.zeros_like(mask), True)
+
+
+def test_largeScaleChain_mp_replay_four_chains_equals_cpu_pool(tmp_path):
+    """BASELINE configs[0] plumbing: 64x64 grid, 4 chains through largeScaleChain_mp in replay mode == what the
+    reference's process pool computes on the CPU (oracle chains on the same seeds), incl. the checkpoint files."""
+    prob, ch, rf = synthetic.template(64)
+    seeds = [101, 202, 303, 404]
+    beds = list(synthetic.initial_beds(prob, 4))
+    res = driver.largeScaleChain_mp(4, 7, ch, rf, beds, seeds, [200] * 4, output_path=str(tmp_path))
+    p2, cfg, pairs, masks, rfp = orc.standard_setup(64)
+    for i, s in enumerate(seeds):
+        o = orc.run_chain(cfg, beds[i].copy(), 200, orc.OracleRandField(rfp, s, pairs, masks, 500.0), np.random.default_rng(s))
+        assert np.array_equal(res[i][0], o[0]) and np.array_equal(res[i][4], o[4])
+        np.testing.assert_allclose(res[i][3], o[3], rtol=RTOL)
+        assert np.array_equal(res[i][6], o[6], equal_nan=True) and np.array_equal(res[i][5], o[5])
+        folder = tmp_path / "LargeScaleChain" / str(s)[:6]
+        assert sorted(p.name for p in folder.iterdir()) == ["RNGState_RandField.txt", "RNGState_chain.txt",
+                                                            "RNGState_philox.txt", "bed_0k.npy", "current_iter.txt",
+                                                            "results_0k.npz"]
+        assert np.array_equal(np.load(folder / "bed_0k.npy"), o[0])
+
+
+def test_ieee_division_path_when_resolution_has_all_ones_significand():
+    """exact_div is switched off by the host for a divisor whose significand is all ones; the IEEE-division
+    instantiation of the step kernel must give the same parity."""
+    from mcmc_gpu_amd.engine import GsmEngine
+    res = float(np.nextafter(512.0, 0.0))          # 0x1.fffffffffffffp+8
+    prob, cfg, pairs, masks, rfp = orc.standard_setup(64)
+    cfg.resolution = res
+    masks = orc.edge_masks(pairs, [2, 0, 6, 1], 49900.0, res)
+    eng = GsmEngine(64, 64, 1)
+    eng.set_static(cfg.surf, cfg.velx, cfg.vely, cfg.dhdt, cfg.smb, cfg.crf_data_weight, cfg.region_mask,
+                   cfg.mc_region_mask, res, cfg.sigma_mc)
+    eng.set_blocks(pairs, masks)
+    rf = orc.OracleRandField(rfp, 13, pairs, masks, res)
+    out = orc.run_chain(cfg, prob["bed"].copy(), 150, rf, np.random.default_rng(13), record=True)
+    tr = out[7]
+    eng.set_state(prob["bed"][None])
+    loss, acc = eng.run_replay(np.array([tr.size_idx]), np.array([tr.centre]), np.array([tr.u]), eng.pack_fields([tr.fields]))
+    assert np.array_equal(acc[0], out[4][1:].astype(np.uint8))
+    np.testing.assert_allclose(loss[0], out[3][1:], rtol=RTOL)
+    assert np.array_equal(eng.beds[0].cpu().numpy(), out[0])
+    eng.close()
