@@ -193,6 +193,37 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
 
+    # the two kernels co-run on two streams in the timed region, which stretches each one's duration; time one launch of
+    # each ALONE as well (outside the timed region) so the roofline can be read both ways
+    iso = None
+    if args.generator == "spectral":
+        import ctypes as C
+        from mcmc_gpu_amd.engine import _ptr
+        nrec = n_local * batch
+        t_si = torch.empty(nrec, dtype=torch.int32, device=dev); t_ce = torch.empty(2 * nrec, dtype=torch.int32, device=dev)
+        t_u = torch.empty(nrec, dtype=torch.float64, device=dev)
+        t_f = torch.empty((nrec, eng.field_stride), dtype=torch.float64, device=dev)
+        t_l = torch.empty(nrec, dtype=torch.float64, device=dev); t_a = torch.empty(nrec, dtype=torch.uint8, device=dev)
+        d_seeds = eng._seeds(seeds)
+        tp, ts, ab = [], [], []
+        for r in range(3):
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            eng._check(eng.lib.gsm_propose_philox(eng.h, batch, step0 + r * batch, _ptr(d_seeds), C.byref(p), _ptr(t_si), _ptr(t_ce),
+                                                  _ptr(t_u), _ptr(t_f), eng.field_stride, None, eng._stream()))
+            e1.record()
+            eng._check(eng.lib.gsm_run_replay(eng.h, batch, _ptr(eng.beds), _ptr(eng.energy), _ptr(eng.resampled), _ptr(eng.loss_sum),
+                                              _ptr(t_si), _ptr(t_ce), _ptr(t_u), _ptr(t_f), eng.field_stride, _ptr(t_l), _ptr(t_a),
+                                              eng._stream()))
+            e2.record(); torch.cuda.synchronize(dev)
+            tp.append(e0.elapsed_time(e1)); ts.append(e1.elapsed_time(e2))
+            si_h = t_si.cpu().numpy()
+            b_h = np.concatenate([t_ce.view(n_local, batch, 2).cpu().numpy(), eng.bh[si_h].reshape(n_local, batch, 1),
+                                  eng.bw[si_h].reshape(n_local, batch, 1)], axis=2)
+            ab.append(algorithmic_bytes(b_h, t_a.view(n_local, batch).cpu().numpy(), H, H, 8 if args.state == "f64" else 4))
+        iso = {"step_kernel_ms": float(np.median(ts)), "propose_kernel_ms": float(np.median(tp)), "bytes_per_launch": float(np.mean(ab))}
+        del t_f
+
     chain_steps = n_total * n_timed
     value = chain_steps / elapsed
     if rank == 0:
@@ -208,6 +239,11 @@ def main():
                 "algorithmic_bytes_per_chain_step": bytes_total / (n_local * n_timed),
                 "bytes_per_launch": bytes_per_launch,
                 "step_kernel_ms": step_ms, "propose_kernel_ms": prop_ms, "launches": n_step_l}
+        if iso is not None:
+            for k in ("step_kernel", "propose_kernel"):
+                iso[k + "_frac"] = iso["bytes_per_launch"] / (iso[k + "_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            iso["note"] = "one launch of each kernel alone on an idle GPU (torch events), outside the timed region"
+            roof["isolated"] = iso
         if args.generator == "cholesky":
             # algorithmic flops per chain-step = (bh*bw)^2 (lower-triangular L z)
             nn = (blocks_h[..., 2].astype(np.float64) * blocks_h[..., 3]) ** 2

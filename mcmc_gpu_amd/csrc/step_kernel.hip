@@ -262,7 +262,9 @@ size_t step_lds_bytes(int tile_cap) { return ((size_t)tile_cap + 3 * 16) * sizeo
 
 template <typename TS, int NT, int KMAX, int MINW>
 static hipError_t launch_step_t(const StepArgs& a, hipStream_t st) {
-  const size_t lds = step_lds_bytes(a.tile_cap);
+  size_t lds = step_lds_bytes(a.tile_cap);
+  { static long pad = -1; if (pad < 0) { const char* v = getenv("GSM_STEP_LDS_PAD"); pad = v ? atol(v) : 0; }
+    if ((size_t)pad > lds) lds = (size_t)pad; }
   auto kfast = step_kernel<TS, NT, KMAX, true, MINW>;
   auto kslow = step_kernel<TS, NT, KMAX, false, MINW>;
   static bool attr_set = false;
