@@ -68,7 +68,9 @@ struct StepArgs {
 struct PropScalars {
   double scale, nug, range_x, range_y, u;
   double aa, m_const, m_kappa;   // spectral-amplitude parameters (MCMC.py:209-239)
-  int32_t si, row, col, pad;
+  int32_t si, row, col, bh;
+  int32_t bw, fy_off, g_off, pad;   // block shape and DFT-table offsets: no dependent table look-ups in propose_kernel
+  int64_t mask_off;
 };
 
 struct ProposeArgs {

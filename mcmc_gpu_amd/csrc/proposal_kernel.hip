@@ -109,6 +109,11 @@ __global__ __launch_bounds__(256) void propose_scalars_kernel(const ProposeArgs 
     r.m_kappa = 2.0 * nu / (r.aa * r.aa);
   }
   r.pad = 0;
+  r.bh = a.B.bh[r.si];
+  r.bw = a.B.bw[r.si];
+  r.fy_off = a.fy_off[r.bh];
+  r.g_off = a.g_off[r.bw];
+  r.mask_off = a.B.mask_off[r.si];
   a.scalars[rec] = r;
   a.size_idx[rec] = r.si;
   a.centre[2 * rec] = r.row;
@@ -157,10 +162,10 @@ __global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a
   const int64_t rec = (int64_t)chain * a.n_steps + s;
   const gsm_rf_params& P = a.rf;
   const PropScalars sc = a.scalars[rec];
-  const int si = sc.si;
-  const int bh = a.B.bh[si], bw = a.B.bw[si];
+  const int bh = sc.bh, bw = sc.bw;
   const int hh = bh / 2, hw = bw / 2;
   const int ncol = hw + 1, nrow = hh + 1;
+  if (a.dbg & 64) { if (tid == 0) a.fields[rec * a.field_stride] = (double)bh; return; }
 
   // padded GEMM dimensions (host builds the tables with the same formulas)
   const int KR = (nrow + 3) & ~3;          // stage-1 K  (ky <= hh)
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a
     }
     const int nitem = nrow * ncol;
     const uint32_t m_nc = pmagic((uint32_t)ncol);
-    for (int i = tid; i < nitem; i += kPBlock) {
+    for (int i = tid; i < nitem && !(a.dbg & 32); i += kPBlock) {
       const int ky = (int)__umulhi((uint32_t)i, m_nc);
       const int kx = i - ky * ncol;
       const int kyc = bh - ky;
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a
   const int n_mt = M1 >> 4, n_nt = NR >> 4;
   const int n_t1 = n_mt * n_nt;
   {
-    const double* __restrict__ FC = a.tables + a.fy_off[bh];   // [KR][NR]
+    const double* __restrict__ FC = a.tables + sc.fy_off;      // [KR][NR]
     const double* __restrict__ FS = FC + KR * NR;
 #pragma unroll
     for (int j = 0; j < kMaxT1; ++j) {
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a
   const int n_mt2 = N1 >> 4, n_nt2 = M1 >> 4;
   const int n_t2 = n_mt2 * n_nt2;
   {
-    const double* __restrict__ GC = a.tables + a.g_off[bw];    // [Kc][M1]
+    const double* __restrict__ GC = a.tables + sc.g_off;       // [Kc][M1]
     const double* __restrict__ GS = GC + Kc * M1;
 #pragma unroll
     for (int j = 0; j < kMaxT2; ++j) {
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a
       part += v1 + v2;
     }
   }
-  const double mean = block_sum(part, red, tid) * inv_n;
+  const double mean = (a.dbg & 16) ? part : block_sum(part, red, tid) * inv_n;
   part = 0.0;
 #pragma unroll
   for (int j = 0; j < kMaxT2; ++j) {
@@ -335,11 +340,11 @@ __global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a
       if (ok && x > 0 && x < hw) { const double d = fo[j][q] - mean; part += d * d; }
     }
   }
-  const double sd = sqrt(block_sum(part, red, tid) * inv_n);
+  const double sd = (a.dbg & 16) ? part : sqrt(block_sum(part, red, tid) * inv_n);
   const double gain = sc.scale / (sd + 1e-12);
 
   // ---- scale, nugget (MCMC.py:251), edge mask (MCMC.py:778), store ------------------------------
-  const double* __restrict__ mask = a.B.masks + a.B.mask_off[si];
+  const double* __restrict__ mask = a.B.masks + sc.mask_off;
   double* __restrict__ out = a.fields + rec * a.field_stride;
   const double sq_nug = sqrt(sc.nug);
   const bool with_nugget = (P.nugget_max > 0.0);
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(kPBlock, 2) void propose_kernel(const ProposeArgs a
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int y = 16 * mt + l4 + 4 * q;
-      if ((t < n_t2) && (y < bh) && (x <= hw)) {
+      if ((t < n_t2) && (y < bh) && (x <= hw) && !(a.dbg & 8)) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           if (half == 1 && !(x > 0 && x < hw)) continue;
