@@ -23,7 +23,8 @@
 //               thickness guard, and sum the carried e of the window          -- 1 barrier
 //            D  5-point stencil on the LDS tile -> e_new kept in registers, summed
 //            R  workgroup reduction, every thread evaluates the same accept test -- 1 barrier
-//            E  on accept: write bed window, e window, bump resampled           -- 1 barrier
+//            E  on accept: write bed window, e window, bump resampled           -- 1 barrier (a full fence only
+//               when the next step's halo window overlaps this window; see the end of the step loop)
 // HBM bytes per chain-step: read (bh+2)(bw+2) bed + bh*bw e + bh*bw f; on accept write bh*bw bed + bh*bw e and
 // read-modify-write bh*bw uint32.  Static fields are shared by all chains and stay in L2 / Infinity Cache.
 
@@ -109,11 +110,24 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
   double s_hi = a.loss_sum[2 * chain], s_lo = a.loss_sum[2 * chain + 1];
   double loss_prev = (s_hi + s_lo) / S.two_sigma2;
 
+  // block-size table -> LDS once; per-step scalars are fetched one step ahead (the end-of-step fence below needs the
+  // next window before the step ends)
+  int* tab = (int*)(red + 3 * 16);
+  for (int i = tid; i < a.B.n_sizes; i += NT) { tab[2 * i] = a.B.bh[i]; tab[2 * i + 1] = a.B.bw[i]; }
+  const int64_t rin0 = (int64_t)chain * a.in_stride;
+  int n_si = a.size_idx[rin0], n_row = a.centre[2 * rin0], n_col = a.centre[2 * rin0 + 1];
+  double n_u = a.u[rin0];
+  __syncthreads();
+
   for (int s = 0; s < a.n_steps; ++s) {
-    const int64_t rin = (int64_t)chain * a.in_stride + s;
+    const int64_t rin = rin0 + s;
     const int64_t rout = (int64_t)chain * a.rec_stride + a.rec_offset + s;
-    const int si = a.size_idx[rin];
-    const int row = a.centre[2 * rin], col = a.centre[2 * rin + 1];
+    const int si = n_si, row = n_row, col = n_col;
+    const double uu = n_u;
+    const bool has_next = s + 1 < a.n_steps;
+    if (has_next) {
+      n_si = a.size_idx[rin + 1]; n_row = a.centre[2 * rin + 2]; n_col = a.centre[2 * rin + 3]; n_u = a.u[rin + 1];
+    }
     if (si < 0 || si >= a.B.n_sizes || row < 0 || row >= H || col < 0 || col >= W) {
       if (tid == 0) {
         atomicExch(a.err_flag, 1);
@@ -123,8 +137,7 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
       }
       continue;  // uniform across the workgroup
     }
-    const int bh = a.B.bh[si], bw = a.B.bw[si];
-    const double uu = a.u[rin];
+    const int bh = tab[2 * si], bw = tab[2 * si + 1];
     const double* __restrict__ fld = a.fields + rin * a.field_stride;
 
     // window, clipped to the grid, and the matching sub-block of f (MCMC.py:1266-1276)
@@ -250,7 +263,19 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
       a.accept[rout] = acc ? 1 : 0;
       if (a.blocks) { a.blocks[4 * rout] = row; a.blocks[4 * rout + 1] = col; a.blocks[4 * rout + 2] = bh; a.blocks[4 * rout + 3] = bw; }
     }
-    __syncthreads();  // tile/red reuse + this step's stores visible to the next step's loads
+    // End of step.  The LDS tile / reduction scratch may be reused once every wave is here (raw barrier after the
+    // wave's own LDS reads have returned).  The global stores of an accepted step must be visible to the next step's
+    // loads only if the next halo window touches this window; otherwise the workgroup does not wait for them
+    // (__syncthreads() would: its release fence drains vmcnt, one exposed HBM round trip per step).
+    bool fence = acc;
+    if (fence && has_next && (unsigned)n_si < (unsigned)a.B.n_sizes) {
+      const int nbh = tab[2 * n_si], nbw = tab[2 * n_si + 1];
+      const int nr0 = max(0, n_row - nbh / 2) - 1, nr1 = min(H, n_row + nbh / 2) + 1;
+      const int nc0 = max(0, n_col - nbw / 2) - 1, nc1 = min(W, n_col + nbw / 2) + 1;
+      fence = (nr0 < r1) && (r0 < nr1) && (nc0 < c1) && (c0 < nc1);
+    }
+    if (fence) __syncthreads();
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   if (tid == 0) {
     a.loss_sum[2 * chain] = s_hi;
@@ -258,7 +283,7 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
   }
 }
 
-size_t step_lds_bytes(int tile_cap) { return ((size_t)tile_cap + 3 * 16) * sizeof(double); }
+size_t step_lds_bytes(int tile_cap) { return ((size_t)tile_cap + 3 * 16 + 64) * sizeof(double); }  // tile + reduction + size table (<= 64 sizes)
 
 template <typename TS, int NT, int KMAX, int MINW>
 static hipError_t launch_step_t(const StepArgs& a, hipStream_t st) {
