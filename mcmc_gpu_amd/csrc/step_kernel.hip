@@ -31,6 +31,7 @@
 #include "gsm_internal.h"
 #include <math.h>
 #include <stdlib.h>
+#include <algorithm>
 
 namespace gsm {
 
@@ -89,6 +90,7 @@ __device__ __forceinline__ void two_sum(double a, double b, double& s, double& e
 template <typename TS, int NT, int KMAX, bool FAST_DIV, int MINW>
 __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
   constexpr bool F32 = sizeof(TS) == 4;
+  constexpr bool DEEP = (MINW * 256 / NT) <= 1;   // one workgroup per CU: registers to spare for deep load batching
   constexpr int NW = NT / 64;
   extern __shared__ double lds[];
   double* tile = lds;
@@ -156,6 +158,48 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
     // ---- A: candidate bed -> LDS, guard, sum of the carried energy of the window ------------------
     double acc_old = 0.0;
     int guard = 0;
+    if (DEEP) {
+      // deep variant (one workgroup per CU, 128-VGPR budget): every HBM-latency load of the step (bed, energy, f)
+      // is issued before the first is consumed -- one exposed HBM round trip instead of one per unrolled pair
+      constexpr int KT = KMAX + 1;           // tile cells per thread: (bh+2)(bw+2) <= (KMAX + 1) * NT (host-checked)
+      double vb[KT], vf[KT], ve[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const int i = tid + k * NT;
+        vb[k] = 0.0; vf[k] = 0.0; ve[k] = 0.0;
+        if (i < ncell) {
+          const int lr = (int)__umulhi((uint32_t)i, m_tw);
+          const int lc = i - lr * tw;
+          const int g = (hr0 + lr) * W + hc0 + lc;
+          vb[k] = (double)__builtin_nontemporal_load(&bed[g]);
+          const int wr = lr - dr, wc = lc - dc;
+          if ((unsigned)wr < (unsigned)wh && (unsigned)wc < (unsigned)ww) {
+            ve[k] = (double)__builtin_nontemporal_load(&energy[g]);
+            vf[k] = __builtin_nontemporal_load(&fld[(mr0 + wr) * bw + mc0 + wc]);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KT; ++k) acc_old += ve[k];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const int i = tid + k * NT;
+        if (i < ncell) {
+          const int lr = (int)__umulhi((uint32_t)i, m_tw);
+          const int lc = i - lr * tw;
+          const int g = (hr0 + lr) * W + hc0 + lc;
+          double v = vb[k];
+          const int wr = lr - dr, wc = lc - dc;
+          if ((unsigned)wr < (unsigned)wh && (unsigned)wc < (unsigned)ww && S.upd[g]) {
+            const double pert = S.weight ? vf[k] * S.weight[g] : vf[k];
+            v = v + pert;
+            if (F32) v = (double)(float)v;
+            if (svx[g].x - v <= 0.0) guard = 1;
+          }
+          tile[i] = v;
+        }
+      }
+    } else {
 #pragma unroll 2
     for (int i = tid; i < ncell; i += NT) {
       const int lr = (int)__umulhi((uint32_t)i, m_tw);
@@ -174,6 +218,7 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
         }
       }
       tile[i] = v;
+    }
     }
     __syncthreads();
 
@@ -306,7 +351,8 @@ static hipError_t launch_step_t(const StepArgs& a, hipStream_t st) {
 
 hipError_t launch_step(const StepArgs& a, hipStream_t st) {
   // window cells per thread: the largest block of the table decides the instantiation
-  const int max_win = a.B.max_bh * a.B.max_bw;
+  // (window cells <= KMAX * NT and tile cells <= (KMAX + 1) * NT)
+  const int max_win = std::max(a.B.max_bh * a.B.max_bw, a.tile_cap - 1024);
   static int variant = -1;
   if (variant < 0) { const char* v = getenv("GSM_STEP_VARIANT"); variant = v ? atoi(v) : 1; }
   if (a.f32_state) {
