@@ -221,3 +221,25 @@ def test_ieee_division_path_when_resolution_has_all_ones_significand():
     np.testing.assert_allclose(loss[0], out[3][1:], rtol=RTOL)
     assert np.array_equal(eng.beds[0].cpu().numpy(), out[0])
     eng.close()
+
+
+def test_philox_single_chain_run_equals_batched_run(tmp_path):
+    """chain.run(rng_mode='philox') (one chain per handle, the per-chain wrapper path taken when the chains of a
+    launch have different lengths) gives the same chain as the batched run_many on the same key and counters."""
+    prob, ch, rf = synthetic.template(64)
+    ch.set_rng_mode("philox", philox_batch=8)
+    seeds = [515151, 626262]
+    beds = list(synthetic.initial_beds(prob, 2))
+    res = driver.largeScaleChain_mp(2, 7, ch, rf, beds, seeds, [120, 90], output_path=str(tmp_path))
+    many = MCMC_gpu.run_many(ch, rf, np.stack(beds), seeds, 120, batch=8)
+    assert np.array_equal(res[0][0], many[0][0]) and np.array_equal(res[0][4], many[0][4])
+    np.testing.assert_array_equal(res[0][3], many[0][3])
+    # the shorter chain is a prefix of the same Philox sequence
+    assert np.array_equal(res[1][4], many[1][4][:90]) and np.array_equal(res[1][6], many[1][6][:90], equal_nan=True)
+    st = json.load(open(tmp_path / "LargeScaleChain" / "626262" / "RNGState_philox.txt"))
+    assert st == {"key": 626262, "step": 89}
+    # keep every bed in philox mode
+    c2, r2, _, _ = _rehydrate(ch, rf, 515151, beds[0].copy())
+    c2.set_rng_mode("philox")
+    out = c2.run(20, r2, only_save_last_bed=False, plot=False, progress_bar=None)
+    assert out[0].shape == (20, 64, 64) and np.array_equal(out[0][-1], MCMC_gpu.run_many(ch, rf, beds[0][None], [515151], 20)[0][0])
