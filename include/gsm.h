@@ -172,6 +172,13 @@ int gsm_last_timing(gsm_handle h, double* step_kernel_ms, int32_t* step_launches
 int gsm_cov_assemble(gsm_handle h, int32_t bh, int32_t bw, double resolution, const gsm_vario* vario,
                      const double* lag_table, double* sigma, int64_t ld, void* stream);
 
+/* In-place Cholesky factorisation, upper form: on entry a [dev, n*ld] holds a symmetric positive-definite matrix
+ * (only its upper triangle is read), on exit its upper triangle holds U with U^T U = A + jitter*I and the strict lower
+ * triangle is zero.  n must be a multiple of 64 (pad with an identity block).  Setup-time helper of the Cholesky
+ * proposal generator (blocked right-looking, panel updates on the fp64 matrix cores); synchronises the stream.
+ * GSM_E_ARG with the failing pivot in gsm_last_error when the matrix is not positive definite. */
+int gsm_cholesky_upper(gsm_handle h, double* a, int32_t n, int64_t ld, double jitter, void* stream);
+
 /* Precomputed factors of the Cholesky proposal generator: for block size i and range class r,
  * factors[i*n_classes + r] [host array of dev pointers] is U = chol(Sigma + jitter I)^T, upper triangular,
  * row-major [Npad][Npad] with Npad = N rounded up to 64 and zero padding.  The matrices stay caller-owned.

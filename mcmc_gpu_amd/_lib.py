@@ -115,6 +115,7 @@ def load() -> C.CDLL:
     lib.gsm_enable_timing.argtypes = [vp, i32]
     lib.gsm_last_timing.argtypes = [vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(dbl), C.POINTER(i32)]
     lib.gsm_cov_assemble.argtypes = [vp, i32, i32, dbl, C.POINTER(Vario), vp, vp, i64, vp]
+    lib.gsm_cholesky_upper.argtypes = [vp, vp, i32, i64, dbl, vp]
     lib.gsm_set_factors.argtypes = [vp, i32, C.POINTER(vp), vp]
     lib.gsm_min_dist_from_mask.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.gsm_debug_stream_copy.argtypes = [vp, vp, i64, vp]

@@ -76,16 +76,28 @@ def cov_assemble(eng, bh, bw, res, v: dict, ld=None) -> torch.Tensor:
     return sigma
 
 
-def factor_upper_padded(sigma: torch.Tensor, jitter: float) -> torch.Tensor:
-    """U = chol(Sigma + jitter I)^T zero-padded to [Npad, Npad], Npad = N rounded up to 64 (setup time)."""
+def factor_upper_padded(eng, sigma: torch.Tensor, jitter: float, use_torch: bool = False) -> torch.Tensor:
+    """U = chol(Sigma + jitter I)^T zero-padded to [Npad, Npad], Npad = N rounded up to 64 (setup time).
+    Default: the library's own blocked Cholesky (gsm_cholesky_upper); use_torch=True cross-checks with
+    torch.linalg.cholesky."""
     N = sigma.shape[0]
-    A = sigma[:, :N].clone()
-    A.diagonal().add_(jitter)
-    L = torch.linalg.cholesky(A)
     Np = (N + 63) // 64 * 64
+    if use_torch:
+        A = sigma[:, :N].clone()
+        A.diagonal().add_(jitter)
+        U = torch.zeros((Np, Np), dtype=torch.float64, device=sigma.device)
+        U[:N, :N] = torch.linalg.cholesky(A).T
+        return U.contiguous()
     U = torch.zeros((Np, Np), dtype=torch.float64, device=sigma.device)
-    U[:N, :N] = L.T
-    return U.contiguous()
+    U[:N, :N] = sigma[:, :N]
+    if Np > N:
+        idx = torch.arange(N, Np, device=sigma.device)
+        U[idx, idx] = 1.0 - jitter               # identity block in the padding (factor = 1, removed below)
+    with torch.cuda.device(eng.dev):
+        eng._check(eng.lib.gsm_cholesky_upper(eng.h, _ptr(U), Np, Np, float(jitter), eng._stream()))
+    if Np > N:
+        U[idx, idx] = 0.0
+    return U
 
 
 def class_ranges(rf, n_classes):
@@ -112,7 +124,7 @@ def build_factors(eng, rf, n_classes=1, jitter=1e-8):
         bh, bw = int(eng.bh[i]), int(eng.bw[i])
         for v in varios:
             sigma = cov_assemble(eng, bh, bw, rf.resolution, v)
-            factors.append(factor_upper_padded(sigma, jitter * v["sill"]))
+            factors.append(factor_upper_padded(eng, sigma, jitter * v["sill"]))
             del sigma
     ptrs = (C.c_void_p * len(factors))(*[f.data_ptr() for f in factors])
     with torch.cuda.device(eng.dev):

@@ -8,7 +8,7 @@
 //   cov_assemble_kernel     Sigma[a][b] = cov(|| (coord_a - coord_b) @ R ||), coord = (j*res, i*res) of block cells
 //                           -> _krige.make_sigma.  Matern takes its values from a host lag table (scipy.special.kv,
 //                           as covariance.py:17-22 does); the closed-form models are evaluated here.
-//   (host)                  U = chol(Sigma + jitter I)^T, once per (block size, range class): setup, not hot path.
+//   chol_*_kernel           U = chol(Sigma + jitter I)^T, once per (block size, range class): setup, not hot path.
 //   cz_group_* / cz_zgen    bucket the proposals of a launch by (size, range class); draw z ~ N(0, I) (Philox).
 //   cz_gemm_kernel          F^T[p][n] = sum_{k <= n} Z[k][p] U[k][n] on the fp64 matrix cores
 //                           (v_mfma_f64_16x16x4_f64, 64x64 block tiles staged through LDS, triangular K range),
@@ -23,6 +23,7 @@
 namespace gsm {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int kTS = 80;   // LDS row stride in doubles (== 16 mod 32: conflict-free fragment reads)
 
 // ---------------------------------------------------------------------------------------------------
 // covariance assembly
@@ -192,7 +193,6 @@ __global__ __launch_bounds__(256) void cz_zgen_kernel(const ProposeArgs a, const
 // ---------------------------------------------------------------------------------------------------
 // F^T = Z^T U  (block tile 64 proposals x 64 cells, 4 waves of 32x32, K step 16, LDS double buffer)
 // ---------------------------------------------------------------------------------------------------
-constexpr int kTS = 80;   // LDS row stride in doubles (== 16 mod 32: conflict-free fragment reads)
 
 __global__ __launch_bounds__(256) void cz_gemm_kernel(const ProposeArgs a, const CholArgs c) {
   __shared__ double As[2][16][kTS];
@@ -267,6 +267,125 @@ __global__ __launch_bounds__(256) void cz_gemm_kernel(const ProposeArgs a, const
         }
       }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// In-place blocked Cholesky, upper form: A = U^T U, A row-major [n][ld], n a multiple of 64 (setup time; one
+// factor per block size and range class).  Right-looking, 64-wide panels:
+//   chol_diag_kernel    U_kk = chol(A_kk) in LDS (one workgroup), lower triangle of the block zeroed
+//   chol_panel_kernel   A[k, j] <- U_kk^{-T} A[k, j] for the block columns j > k (one thread per column, U_kk in LDS)
+//   chol_update_kernel  A[i, j] -= U[k, i]^T U[k, j] for k < i <= j on the fp64 matrix cores (64x64 tiles, K = 64)
+// A non-positive pivot sets *info (1-based pivot index) and the factorisation is abandoned by the host.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kCB = 64;
+
+__global__ __launch_bounds__(kCB) void chol_diag_kernel(double* __restrict__ A, int ld, int k0, double jitter, int* info) {
+  __shared__ double a[kCB][kCB + 1];
+  const int c = threadIdx.x;
+  for (int r = 0; r < kCB; ++r) a[r][c] = A[(size_t)(k0 + r) * ld + k0 + c] + ((r == c) ? jitter : 0.0);
+  __syncthreads();
+  for (int s = 0; s < kCB; ++s) {
+    const double piv = a[s][s];
+    if (!(piv > 0.0)) { if (c == 0) atomicCAS(info, 0, k0 + s + 1); return; }   // uniform: every thread reads the same pivot
+    const double d = sqrt(piv);
+    __syncthreads();
+    if (c >= s) a[s][c] = (c == s) ? d : a[s][c] / d;
+    __syncthreads();
+    if (c > s)
+      for (int r = s + 1; r <= c; ++r) a[r][c] -= a[s][r] * a[s][c];
+    __syncthreads();
+  }
+  for (int r = 0; r < kCB; ++r) A[(size_t)(k0 + r) * ld + k0 + c] = (c >= r) ? a[r][c] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, int ld, int n, int k0) {
+  __shared__ double u[kCB][kCB + 1];
+  for (int t = threadIdx.x; t < kCB * kCB; t += 256) u[t / kCB][t % kCB] = A[(size_t)(k0 + t / kCB) * ld + k0 + t % kCB];
+  __syncthreads();
+  const int c = k0 + kCB + blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  double x[kCB];
+#pragma unroll
+  for (int r = 0; r < kCB; ++r) {
+    double v = A[(size_t)(k0 + r) * ld + c];
+#pragma unroll
+    for (int q = 0; q < r; ++q) v -= u[q][r] * x[q];
+    x[r] = v / u[r][r];
+  }
+#pragma unroll
+  for (int r = 0; r < kCB; ++r) A[(size_t)(k0 + r) * ld + c] = x[r];
+}
+
+// one workgroup per (i, j) tile pair with k < i <= j; blockIdx.x enumerates the pairs of the trailing triangle
+__global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A, int ld, int k0, int nt_trail) {
+  __shared__ double Pi[kCB][kTS];
+  __shared__ double Pj[kCB][kTS];
+  // pair index -> (ti <= tj) in the trailing nt_trail x nt_trail block grid
+  int p = blockIdx.x, ti = 0;
+  while (p >= nt_trail - ti) { p -= nt_trail - ti; ++ti; }
+  const int tj = ti + p;
+  const int i0 = k0 + kCB * (1 + ti), j0 = k0 + kCB * (1 + tj);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  for (int t = tid; t < kCB * 16; t += 256) {          // 64 rows x 16 groups of 4 doubles
+    const int r = t >> 4, c4 = (t & 15) * 4;
+    const double* pi = A + (size_t)(k0 + r) * ld + i0 + c4;
+    const double* pj = A + (size_t)(k0 + r) * ld + j0 + c4;
+    *(double2*)&Pi[r][c4] = *(const double2*)pi; *(double2*)&Pi[r][c4 + 2] = *(const double2*)(pi + 2);
+    *(double2*)&Pj[r][c4] = *(const double2*)pj; *(double2*)&Pj[r][c4 + 2] = *(const double2*)(pj + 2);
+  }
+  __syncthreads();
+  const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+  v4f64 acc[2][2];
+#pragma unroll
+  for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < 2; ++b_) acc[a_][b_] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int kk = 0; kk < kCB; kk += 4) {
+    const double a0 = Pi[kk + l4][wm + l15], a1 = Pi[kk + l4][wm + 16 + l15];
+    const double b0 = Pj[kk + l4][wn + l15], b1 = Pj[kk + l4][wn + 16 + l15];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = i0 + wm + 16 * a_ + l4 + 4 * q;
+#pragma unroll
+      for (int b_ = 0; b_ < 2; ++b_) {
+        const int nn = j0 + wn + 16 * b_ + l15;
+        if (nn >= m) A[(size_t)m * ld + nn] -= acc[a_][b_][q];   // upper triangle only
+      }
+    }
+}
+
+// zero the strict lower triangle (the update touches only the upper one) -- cosmetic for callers that read U whole
+__global__ __launch_bounds__(256) void chol_clear_lower_kernel(double* __restrict__ A, int ld, int n) {
+  const int64_t total = (int64_t)n * n;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int r = (int)(t / n), c = (int)(t - (int64_t)r * n);
+    if (c < r) A[(size_t)r * ld + c] = 0.0;
+  }
+}
+
+hipError_t launch_cholesky_upper(double* A, int n, int ld, double jitter, int* d_info, hipStream_t st) {
+  const int nb = n / kCB;
+  for (int k = 0; k < nb; ++k) {
+    const int k0 = k * kCB;
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(kCB), 0, st, A, ld, k0, jitter, d_info);
+    const int rem = n - k0 - kCB;
+    if (rem > 0) {
+      hipLaunchKernelGGL(chol_panel_kernel, dim3((rem + 255) / 256), dim3(256), 0, st, A, ld, n, k0);
+      const int nt = rem / kCB;
+      hipLaunchKernelGGL(chol_update_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, A, ld, k0, nt);
+    }
+  }
+  hipLaunchKernelGGL(chol_clear_lower_kernel, dim3(2048), dim3(256), 0, st, A, ld, n);
+  return hipGetLastError();
 }
 
 hipError_t launch_propose_cholesky(const ProposeArgs& a, const CholArgs& c, hipStream_t st) {

@@ -609,3 +609,23 @@ extern "C" int gsm_min_dist_from_mask(gsm_handle h, const double* xx, const doub
   if (m == 0) return fail(h, GSM_E_ARG, "gsm_min_dist_from_mask: mask selects no cell");
   return GSM_OK;
 }
+
+extern "C" int gsm_cholesky_upper(gsm_handle h, double* a, int32_t n, int64_t ld, double jitter, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!a || n < 64 || (n % 64) != 0 || ld < n || ld > 0x7fffffff)
+    return fail(h, GSM_E_ARG, "gsm_cholesky_upper: n must be a positive multiple of 64 and ld >= n");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, hipMemsetAsync(h->d_err, 0, sizeof(int32_t), st));
+  HIPCHK(h, launch_cholesky_upper(a, n, (int)ld, jitter, h->d_err, st));
+  int32_t info = 0;
+  HIPCHK(h, hipMemcpyAsync(&info, h->d_err, sizeof(info), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (info != 0) {
+    hipMemsetAsync(h->d_err, 0, sizeof(int32_t), st);
+    hipStreamSynchronize(st);
+    return fail(h, GSM_E_ARG, "gsm_cholesky_upper: matrix not positive definite at pivot " + std::to_string(info) +
+                              " (raise the jitter: the Gaussian covariance is numerically singular, SURVEY.md section 7)");
+  }
+  return GSM_OK;
+}

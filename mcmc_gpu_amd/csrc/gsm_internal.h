@@ -117,6 +117,7 @@ struct CholArgs {
 
 // launchers (defined next to their kernels)
 hipError_t launch_propose_cholesky(const ProposeArgs& a, const CholArgs& c, hipStream_t st);
+hipError_t launch_cholesky_upper(double* A, int n, int ld, double jitter, int* d_info, hipStream_t st);
 hipError_t launch_cov_assemble(int bh, int bw, double res, const gsm_vario& v, const double* lag_table, double* sigma,
                                int ld, hipStream_t st);
 hipError_t launch_step(const StepArgs& a, hipStream_t st);

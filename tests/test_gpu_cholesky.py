@@ -81,3 +81,32 @@ def test_cholesky_chain_runs_and_is_batch_independent():
     lc, ac = eng.run_replay(p["size_idx"].cpu().numpy(), p["centre"].cpu().numpy(), p["u"].cpu().numpy(), p["fields"])
     assert np.array_equal(aa, ac) and np.array_equal(la, lc)
     eng.close()
+
+
+def test_library_cholesky_matches_lapack():
+    """gsm_cholesky_upper (blocked, MFMA trailing updates) against torch.linalg.cholesky / numpy on the covariance of
+    a 50x56 block (N = 2800, padded to 2816) and on a small well-conditioned matrix; non-PD input is reported."""
+    import torch
+    from mcmc_gpu_amd._lib import GsmError
+    eng, prob, *_ = make_engine(64, 1)
+    v = chol.make_vario("Exponential", 20e3, 15e3, azimuth=20.0)
+    sigma = chol.cov_assemble(eng, 50, 56, 500.0, v)
+    U = chol.factor_upper_padded(eng, sigma, 1e-8)
+    Ut = chol.factor_upper_padded(eng, sigma, 1e-8, use_torch=True)
+    N = 2800
+    assert U.shape == (2816, 2816) and torch.count_nonzero(U[N:, :]) == 0 and torch.count_nonzero(U[:, N:]) == 0
+    assert torch.count_nonzero(torch.tril(U, -1)) == 0
+    A = sigma + 1e-8 * torch.eye(N, dtype=torch.float64, device=sigma.device)
+    rec = U[:N, :N].T @ U[:N, :N]
+    assert float((rec - A).abs().max()) < 1e-12
+    assert float((U - Ut).abs().max()) < 1e-9          # cond(Sigma) ~ 1e4: factors agree far below the proposal scale
+    # Matern, through the whole build_factors path already covered by test_cholesky_proposals_match_oracle
+    g = np.random.default_rng(1)
+    M = g.normal(size=(128, 128)); S = M @ M.T + 128 * np.eye(128)
+    t = torch.as_tensor(S).cuda()
+    Us = chol.factor_upper_padded(eng, t, 0.0).cpu().numpy()
+    np.testing.assert_allclose(Us, np.linalg.cholesky(S).T, rtol=0, atol=1e-12)
+    bad = torch.as_tensor(S - 400 * np.eye(128)).cuda()
+    with pytest.raises(GsmError, match="positive definite"):
+        chol.factor_upper_padded(eng, bad, 0.0)
+    eng.close()
