@@ -4,7 +4,6 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
-#include <map>
 
 using namespace gsm;
 

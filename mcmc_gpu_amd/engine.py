@@ -48,7 +48,6 @@ class GsmEngine:
         self.beds = self.energy = self.resampled = self.loss_sum = None
         self.field_stride = 0
         self.n_sizes = 0
-        self._keep = []
 
     # ------------------------------------------------------------------------------------------
     def close(self):

@@ -120,3 +120,31 @@ def test_block_as_large_as_the_grid_and_single_chain():
     with pytest.raises(GsmError):
         eng.set_blocks(np.array([[7], [8]]), None)
     eng.close()
+
+
+def test_large_blocks_use_the_wider_instantiation():
+    """Blocks of 96-110 cells on a 128x128 grid: the step kernel's 12-cells-per-thread instantiation (one workgroup per
+    CU, deep load batching) against the oracle; the spectral proposal kernel refuses such blocks cleanly (its
+    accumulator tiling covers blocks up to about 80x80) while replay keeps working."""
+    from gpu_common import oracle_chains, replay_inputs
+    from mcmc_gpu_amd._lib import GsmError
+    from mcmc_gpu_amd.engine import GsmEngine
+    prob, cfg, pairs, masks, rfp = orc.standard_setup(128, 128, block_min=96, block_max=110)
+    assert pairs.max() == 110
+    eng = GsmEngine(128, 128, 2)
+    eng.set_static(cfg.surf, cfg.velx, cfg.vely, cfg.dhdt, cfg.smb, cfg.crf_data_weight, cfg.region_mask,
+                   cfg.mc_region_mask, cfg.resolution, cfg.sigma_mc)
+    eng.set_blocks(pairs, masks)
+    eng.set_centres(cfg.region_mask)
+    outs = oracle_chains(prob, cfg, pairs, masks, rfp, 2, 60)
+    loss0 = eng.set_state(np.stack([orc.chain_initial_bed(prob, c) for c in range(2)]))
+    loss, acc = eng.run_replay(*replay_inputs(eng, outs))
+    for c, o in enumerate(outs):
+        assert np.array_equal(acc[c], o[4][1:].astype(np.uint8))
+        np.testing.assert_allclose(loss[c], o[3][1:], rtol=1e-10)
+        assert np.array_equal(eng.beds[c].cpu().numpy(), o[0])
+        assert np.array_equal(eng.resampled[c].cpu().numpy().astype(float), o[5])
+    rfp.resolution = prob["resolution"]
+    with pytest.raises(GsmError, match="too large"):
+        eng.propose_philox(2, 0, [1, 2], rfp)
+    eng.close()
