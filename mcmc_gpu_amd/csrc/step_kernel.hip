@@ -36,8 +36,11 @@
 namespace gsm {
 
 __device__ __forceinline__ uint32_t magic_for(uint32_t d) {
-  // q = __umulhi(n, M) == n / d for n*d < 2^32 (here n < 2^16, d < 2^8)
+  // q = __umulhi(n, M) == n / d for n*d < 2^32 (here n < 2^16, 2 <= d < 2^8); d == 1 would need M = 2^32
   return (uint32_t)(0xFFFFFFFFu / d) + 1u;
+}
+__device__ __forceinline__ int div_magic(int n, uint32_t d, uint32_t M) {
+  return (d == 1u) ? n : (int)__umulhi((uint32_t)n, M);   // a 2-wide block clipped at the grid edge is 1 cell wide
 }
 
 // Correctly rounded x / d from y = RN(1/d): q0 = RN(x*y), r = x - q0*d (exact in an fma), q = RN(q0 + r*y)
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
       const int i = tid + k * NT;
       double e = 0.0;
       if (i < nwin) {
-        const int wr = (int)__umulhi((uint32_t)i, m_ww);
+        const int wr = div_magic(i, (uint32_t)ww, m_ww);
         const int wc = i - wr * ww;
         const int r = r0 + wr, c = c0 + wc;
         const int g = r * W + c;
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(NT, MINW) void step_kernel(const StepArgs a) {
       for (int k = 0; k < KMAX; ++k) {
         const int i = tid + k * NT;
         if (i < nwin) {
-          const int wr = (int)__umulhi((uint32_t)i, m_ww);
+          const int wr = div_magic(i, (uint32_t)ww, m_ww);
           const int wc = i - wr * ww;
           const int r = r0 + wr, c = c0 + wc;
           const size_t g = (size_t)r * W + c;
