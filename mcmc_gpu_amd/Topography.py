@@ -39,3 +39,25 @@ def get_mass_conservation_residual(bed, surf, velx, vely, dhdt, smb, resolution)
 def get_mass_conservation_residual_tensor(bed, surf, velx, vely, dhdt, smb, resolution):
     """torch twin (Topography.py:602-612): accepts tensors, returns a cuda float64 tensor."""
     return _residual_device(bed, surf, velx, vely, dhdt, smb, resolution)
+
+
+def get_highvel_boundary(velx, vely, velmag_threshold, grounded_ice_mask, ocean_mask, distance_max, xx, yy,
+                         smooth_mode=10):
+    """High-velocity region mask, smoothed and grown outward by `distance_max` (reference Topography.py:543-571).
+
+    Same steps as the reference: threshold on the speed of grounded ice (plus ocean), PIL mode filter, then every
+    grounded cell closer than `distance_max` to the filtered region.  The reference finds that distance with an
+    O((H*W)^2) Python double loop (:564-566); here it is one call of the exact distance transform
+    (`min_dist_from_mask`: HIP kernel on a GPU machine, KD-tree otherwise) -- SURVEY.md section 8f rank 2."""
+    from PIL import Image, ImageFilter
+    from .MCMC_gpu import min_dist_from_mask
+    grounded = np.asarray(grounded_ice_mask)
+    mask = (grounded) & (np.sqrt(velx ** 2 + vely ** 2) >= velmag_threshold)
+    mask = mask | ocean_mask
+    image = Image.fromarray((mask * 255).astype(np.uint8)).filter(ImageFilter.ModeFilter(size=smooth_mode))
+    mask_mat = np.array(np.array(image) / 255, dtype=int)
+    hard = (mask_mat == 1) & (grounded == 1)
+    if not hard.any():
+        return np.zeros(np.shape(xx), dtype=bool) & grounded
+    dist = min_dist_from_mask(np.asarray(xx, dtype=np.float64), np.asarray(yy, dtype=np.float64), hard)
+    return (dist < distance_max) & grounded

@@ -46,6 +46,14 @@ def quiet():
     return contextlib.redirect_stdout(io.StringIO())
 
 
+@contextlib.contextmanager
+def warnings_off():
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        yield
+
+
 def build_reference_chain(M, prob, cfg_kw, rfp: orc.RFParams, block_min, block_max, sigma=5.0):
     """Template chain + RandField through the reference's own public API."""
     with quiet():
@@ -218,7 +226,19 @@ def main():
     np.savez_compressed(GOLD / "f8_chain256_anchor.npz", H=256, n_iter=120, seed=7, chain_index=0,
                         loss=out8[3], steps=out8[4], blocks=out8[6], bed_sha=sha(out8[0]),
                         resampled_sha=sha(out8[5]), bed_row128=out8[0][128])
-    # torch twin of the reference on the CPU device (fp32): accept masks vs fp64
+    # ---------------- F9: Topography.get_highvel_boundary -----------------
+    g9 = np.random.default_rng(99)
+    H9, W9 = 36, 44
+    xx9, yy9 = np.meshgrid(np.arange(W9) * 450.0 + 1.2e5, np.arange(H9) * 450.0 - 3.0e4)
+    velx9 = 120.0 * np.exp(-((yy9 - yy9.mean()) / 4000.0) ** 2) + g9.normal(0, 5, (H9, W9))
+    vely9 = g9.normal(0, 8, (H9, W9))
+    grounded9 = np.ones((H9, W9), dtype=bool); grounded9[:, :6] = False
+    ocean9 = ~grounded9
+    with warnings_off():
+        hv = T.get_highvel_boundary(velx9, vely9, 60.0, grounded9, ocean9, 2500.0, xx9, yy9, smooth_mode=5)
+    np.savez_compressed(GOLD / "f9_highvel_boundary.npz", velx=velx9, vely=vely9, grounded=grounded9, ocean=ocean9,
+                        xx=xx9, yy=yy9, threshold=60.0, distance_max=2500.0, smooth_mode=5, mask_final=hv)
+
     print("fixtures written to", GOLD)
     for p in sorted(GOLD.iterdir()):
         print(f"  {p.name:40s} {p.stat().st_size:9d} B")

@@ -243,3 +243,10 @@ def test_philox_single_chain_run_equals_batched_run(tmp_path):
     c2.set_rng_mode("philox")
     out = c2.run(20, r2, only_save_last_bed=False, plot=False, progress_bar=None)
     assert out[0].shape == (20, 64, 64) and np.array_equal(out[0][-1], MCMC_gpu.run_many(ch, rf, beds[0][None], [515151], 20)[0][0])
+
+
+def test_highvel_boundary_on_device(golden_dir):
+    g = np.load(golden_dir / "f9_highvel_boundary.npz")
+    m = Topography.get_highvel_boundary(g["velx"], g["vely"], float(g["threshold"]), g["grounded"], g["ocean"],
+                                        float(g["distance_max"]), g["xx"], g["yy"], smooth_mode=int(g["smooth_mode"]))
+    assert np.array_equal(m, g["mask_final"])

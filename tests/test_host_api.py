@@ -193,3 +193,14 @@ def test_philox_oracle_proposal_distribution_matches_reference_spectral():
         cb = np.mean(B[:, :12 - lag[0], :16 - lag[1]] * B[:, lag[0]:, lag[1]:])
         assert abs(ca - cb) < 0.04 * 900.0, (lag, ca, cb)      # variance is scale^2 = 900; MC error ~1-2 %
     assert abs(A.mean()) < 1.0 and abs(B.mean()) < 1.0
+
+
+def test_highvel_boundary_equals_reference(golden_dir):
+    """Topography.get_highvel_boundary (host path: KD-tree distance) against fixture F9 = the reference's
+    O(N^2) double loop on the same inputs."""
+    from mcmc_gpu_amd import Topography
+    g = np.load(golden_dir / "f9_highvel_boundary.npz")
+    m = Topography.get_highvel_boundary(g["velx"], g["vely"], float(g["threshold"]), g["grounded"], g["ocean"],
+                                        float(g["distance_max"]), g["xx"], g["yy"], smooth_mode=int(g["smooth_mode"]))
+    assert m.dtype == bool and np.array_equal(m, g["mask_final"])
+    assert 0 < m.sum() < m.size
