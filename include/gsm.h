@@ -200,6 +200,13 @@ int gsm_min_dist_from_mask(gsm_handle h, const double* xx, const double* yy, con
  * coalesced).  A known byte count for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM). */
 int gsm_debug_stream_copy(const double* src, double* dst, int64_t n, void* stream);
 
+/* Diagnostics: per-chain cycle totals of the step kernel's phases (8 x uint64 per chain, host buffer) from the last
+ * launch.  Only in a library built with GSM_STAMPS=1 (a diagnostic build: the stamps cost cycles); the production build
+ * returns GSM_E_UNSUPPORTED. */
+int gsm_debug_stamps(uint64_t* out, int32_t n_chains);
+/* Same for the fused chain kernel (16 x uint64 per chain). */
+int gsm_debug_stamps_fused(uint64_t* out, int32_t n_chains);
+
 /* Test hook: one Philox4x32-10 block on the host (ctr[4], key[2] -> out[4]); the device generator uses
  * the same inline function.  Checked against the Random123 known-answer vectors. */
 int gsm_philox_selftest(const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4);

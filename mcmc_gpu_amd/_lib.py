@@ -16,9 +16,14 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libgsm_hip.so"
 HEADER = PKG_DIR.parent / "include" / "gsm.h"
-SOURCES = ["gsm_api.hip", "step_kernel.hip", "proposal_kernel.hip", "cholesky_kernel.hip"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+SOURCES = ["gsm_api.hip", "step_kernel.hip", "step_flux_kernel.hip", "chain_fused_kernel.hip", "proposal_kernel.hip", "cholesky_kernel.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-Wno-unused-value", "-Wno-unused-result"]
+# per-file extras.  step_flux_kernel: without machine LICM the fp64 polynomial constants of exp() are materialised at
+# their use instead of being hoisted out of the step loop into ~30 VGPRs that are then spilled.
+EXTRA_FLAGS = {"step_flux_kernel.hip": ["-mllvm", "-disable-machine-licm"],
+               "chain_fused_kernel.hip": ["-mllvm", "-disable-machine-licm"]}
+OBJ_DIR = PKG_DIR / "_build"
 
 
 class GsmError(RuntimeError):
@@ -44,12 +49,27 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libgsm_hip.so")
-    cmd = [hipcc, *HIPCC_FLAGS, "-o", str(LIB_PATH), *[str(CSRC / s) for s in SOURCES]]
-    if verbose:
-        print(" ".join(cmd))
+    OBJ_DIR.mkdir(exist_ok=True)
+    hdr_t = max(p.stat().st_mtime for p in list(CSRC.glob("*.h")) + [HEADER])
+    procs, objs = [], []
+    for s in SOURCES:
+        src, obj = CSRC / s, OBJ_DIR / (s + ".o")
+        objs.append(str(obj))
+        if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_t):
+            continue
+        diag = ["-DGSM_STAMPS"] if os.environ.get("GSM_STAMPS") else []
+        cmd = [hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(s, []), *diag, "-c", "-o", str(obj), str(src)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH), *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
     return LIB_PATH
 
 

@@ -16,6 +16,7 @@ struct gsm_context {
   uint8_t* d_upd = nullptr;
   uint8_t* d_mc = nullptr;
   double2 *d_svx = nullptr, *d_svy = nullptr, *d_ds = nullptr;
+  double2 *d_sA = nullptr, *d_sB = nullptr, *d_sC = nullptr;
   StaticFields S{};
   int32_t *d_bh = nullptr, *d_bw = nullptr;
   int64_t* d_mask_off = nullptr;
@@ -23,6 +24,7 @@ struct gsm_context {
   double* d_tables = nullptr;
   int32_t *d_fy_off = nullptr, *d_g_off = nullptr;
   int lds_sx = 0, lds_st = 0, lds_x_half = 0, lds_tt = 0, prop_tiles = 0, prop_tiles1 = 0;
+  int tables_len = 0, tab_max = 0;
   PropScalars* d_scalars[2] = {nullptr, nullptr};
   size_t scalars_cap[2] = {0, 0};
   // Cholesky generator
@@ -110,6 +112,9 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_svx) hipFree(h->d_svx);
   if (h->d_svy) hipFree(h->d_svy);
   if (h->d_ds) hipFree(h->d_ds);
+  if (h->d_sA) hipFree(h->d_sA);
+  if (h->d_sB) hipFree(h->d_sB);
+  if (h->d_sC) hipFree(h->d_sC);
   if (h->d_bh) hipFree(h->d_bh);
   if (h->d_bw) hipFree(h->d_bw);
   if (h->d_mask_off) hipFree(h->d_mask_off);
@@ -181,9 +186,14 @@ extern "C" int gsm_set_static(gsm_handle h, const double* surf, const double* ve
     HIPCHK(h, hipMalloc(&h->d_svx, n * sizeof(double2)));
     HIPCHK(h, hipMalloc(&h->d_svy, n * sizeof(double2)));
     HIPCHK(h, hipMalloc(&h->d_ds, n * sizeof(double2)));
+    HIPCHK(h, hipMalloc(&h->d_sA, n * sizeof(double2)));
+    HIPCHK(h, hipMalloc(&h->d_sB, n * sizeof(double2)));
+    HIPCHK(h, hipMalloc(&h->d_sC, n * sizeof(double2)));
   }
   HIPCHK(h, launch_pack_static(S, h->d_svx, h->d_svy, h->d_ds, st));
+  HIPCHK(h, launch_pack_flux_static(S, h->d_sA, h->d_sB, h->d_sC, st));
   S.svx = h->d_svx; S.svy = h->d_svy; S.ds = h->d_ds;
+  S.sA = h->d_sA; S.sB = h->d_sB; S.sC = h->d_sC;
   HIPCHK(h, hipStreamSynchronize(st));
   h->have_static = true;
   return GSM_OK;
@@ -272,6 +282,13 @@ extern "C" int gsm_set_blocks(gsm_handle h, int32_t n_sizes, const int32_t* bh, 
   h->lds_x_half = krmax * h->lds_sx;          // one of the four folded coefficient planes
   h->lds_tt = 2 * kcmax * h->lds_st;
   h->prop_tiles = tiles_max;
+  h->tables_len = (int)tb.size();
+  h->tab_max = 0;
+  for (int i = 0; i < n_sizes; ++i) {
+    const int nrow = bh[i] / 2 + 1, ncol = bw[i] / 2 + 1;
+    h->tab_max = std::max(h->tab_max, 2 * ((nrow + 3) & ~3) * ((nrow + 15) & ~15));
+    h->tab_max = std::max(h->tab_max, 2 * ((ncol + 3) & ~3) * ((ncol + 15) & ~15));
+  }
   HIPCHK(h, dup_device(&h->d_tables, tb.data(), tb.size(), st));
   HIPCHK(h, dup_device(&h->d_fy_off, fy_off.data(), fy_off.size(), st));
   HIPCHK(h, dup_device(&h->d_g_off, g_off.data(), g_off.size(), st));
@@ -407,7 +424,7 @@ static ProposeArgs make_propose(gsm_handle h, const gsm_rf_params* rf, int n_ste
   p.B = h->B; p.rf = *rf; p.H = h->H; p.W = h->W;
   p.n_chains = h->n_chains; p.n_steps = n_steps; p.step0 = step0; p.seeds = seeds;
   p.centres = h->d_centres; p.n_centres = h->n_centres;
-  p.tables = h->d_tables; p.fy_off = h->d_fy_off; p.g_off = h->d_g_off;
+  p.tables = h->d_tables; p.tables_len = h->tables_len; p.tab_max = h->tab_max; p.fy_off = h->d_fy_off; p.g_off = h->d_g_off;
   p.lds_sx = h->lds_sx; p.lds_st = h->lds_st; p.lds_x_half = h->lds_x_half; p.lds_tt = h->lds_tt;
   p.lds_main = std::max(4 * h->lds_x_half, h->lds_tt);
   return p;
@@ -467,11 +484,56 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(h, hipSetDevice(h->device));
   if (batch > n_steps) batch = n_steps;
+  // Spectral generator: one fused launch (chain_fused_kernel.hip) -- proposals are generated and consumed on the CU,
+  // no field scratch, no second stream.  GSM_FUSED=0 keeps the two-kernel pipeline (also used by the Cholesky generator
+  // and by block tables beyond the fused kernel's LDS budget).
+  static int use_fused = -1;
+  if (use_fused < 0) { const char* v = getenv("GSM_FUSED"); use_fused = (v && atoi(v) == 0) ? 0 : 1; }
+  if (use_fused && rf->generator == GSM_GEN_SPECTRAL) {
+    FusedArgs fa{};
+    StepArgs& a = fa.T;
+    a.S = h->S; a.B = h->B;
+    a.n_chains = h->n_chains; a.n_steps = n_steps; a.tile_cap = h->tile_cap;
+    a.beds = beds; a.energy = energy; a.f32_state = h->f32_state; a.resampled = resampled; a.loss_sum = loss_sum;
+    a.loss = loss; a.accept = accept; a.blocks = blocks;
+    a.rec_stride = n_steps; a.rec_offset = 0; a.in_stride = n_steps;
+    a.err_flag = h->d_err;
+    { int rc2 = ensure_scalars(h, 0, (size_t)h->n_chains * n_steps); if (rc2) return rc2; }
+    fa.P = make_propose(h, rf, n_steps, step0, seeds);
+    fa.P.scalars = h->d_scalars[0];
+    // the scalars kernel also writes (size_idx, centre, u) records: give it the scalar-sized scratch of slot 1
+    if (fused_supported(fa)) {
+      const size_t recs1 = (size_t)h->n_chains * n_steps;
+      auto& sc = h->scr[1];
+      if (sc.recs < recs1 || sc.fields) {
+        if (sc.size_idx) { hipFree(sc.size_idx); hipFree(sc.centre); hipFree(sc.u); if (sc.fields) hipFree(sc.fields); sc = gsm_context::Scratch(); }
+        HIPCHK(h, hipMalloc(&sc.size_idx, recs1 * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc(&sc.centre, recs1 * 2 * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc(&sc.u, recs1 * sizeof(double)));
+        sc.recs = recs1;
+      }
+      fa.P.size_idx = sc.size_idx; fa.P.centre = sc.centre; fa.P.u = sc.u;
+      hipEvent_t t0 = nullptr, t1 = nullptr;
+      if (h->timing) { HIPCHK(h, hipEventCreate(&t0)); HIPCHK(h, hipEventCreate(&t1)); }
+      HIPCHK(h, launch_propose_scalars(fa.P, st));
+      if (h->timing) HIPCHK(h, hipEventRecord(t0, st));
+      HIPCHK(h, launch_chain_fused(fa, st));
+      if (h->timing) HIPCHK(h, hipEventRecord(t1, st));
+      rc = check_device_flag(h, st, "gsm_run_philox");
+      if (h->timing) {
+        float ms = 0;
+        h->t_step_ms = h->t_prop_ms = 0; h->n_step_launch = h->n_prop_launch = 0;
+        if (hipEventElapsedTime(&ms, t0, t1) == hipSuccess) { h->t_step_ms = ms; h->n_step_launch = 1; }
+        hipEventDestroy(t0); hipEventDestroy(t1);
+      }
+      return rc;
+    }
+  }
   // scratch
   const size_t recs = (size_t)h->n_chains * batch;
   for (auto& s : h->scr) {
-    if (s.recs >= recs) continue;
-    if (s.size_idx) { hipFree(s.size_idx); hipFree(s.centre); hipFree(s.u); hipFree(s.fields); s = gsm_context::Scratch(); }
+    if (s.recs >= recs && s.fields) continue;
+    if (s.size_idx) { hipFree(s.size_idx); hipFree(s.centre); hipFree(s.u); if (s.fields) hipFree(s.fields); s = gsm_context::Scratch(); }
     HIPCHK(h, hipMalloc(&s.size_idx, recs * sizeof(int32_t)));
     HIPCHK(h, hipMalloc(&s.centre, recs * 2 * sizeof(int32_t)));
     HIPCHK(h, hipMalloc(&s.u, recs * sizeof(double)));
@@ -547,6 +609,16 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
     for (auto& e : tev) hipEventDestroy(e);
   }
   return rc;
+}
+
+extern "C" int gsm_debug_stamps(uint64_t* out, int32_t n_chains) {
+  if (!out || n_chains < 1 || n_chains > 4096) return GSM_E_ARG;
+  return debug_read_stamps((unsigned long long*)out, n_chains);
+}
+
+extern "C" int gsm_debug_stamps_fused(uint64_t* out, int32_t n_chains) {
+  if (!out || n_chains < 1 || n_chains > 4096) return GSM_E_ARG;
+  return debug_read_stamps_fused((unsigned long long*)out, n_chains);
 }
 
 extern "C" int gsm_debug_stream_copy(const double* src, double* dst, int64_t n, void* stream) {

@@ -22,6 +22,10 @@ struct StaticFields {
   const double2* svx;     // (surf, velx)
   const double2* svy;     // (surf, vely)
   const double2* ds;      // (dhdt, smb)
+  // folded operands of the flux step kernel (step_flux_kernel.hip): masks encoded as NaNs
+  const double2* sA;      // (crf weight where update_mask else tagged NaN, surf)
+  const double2* sB;      // (velx, vely)
+  const double2* sC;      // (dhdt where mc_mask == 1 else NaN, smb)
   int H, W;
   double res;             // grid spacing h
   double two_res;         // 2.0 * h  (np.gradient interior denominator)
@@ -90,6 +94,8 @@ struct ProposeArgs {
   double* rf_scalars;      // optional
   // DFT operand tables (device), built by gsm_set_blocks; see proposal_kernel.hip for the shapes
   const double* tables;
+  int tables_len;          // doubles in `tables`
+  int tab_max;             // largest single table pair (2*KR*NR or 2*Kc*M1 doubles) over the block table
   const int32_t* fy_off;   // indexed by block height n: offset of [cos | sin](2 pi ky y / n), each [K1][N1]
   const int32_t* g_off;    // indexed by block width n: offset of the folded c2r table G, [K2][N2]
   int lds_sx, lds_st;      // LDS row strides of X and T^T (== 16 mod 32 doubles: conflict-free fragment reads)
@@ -98,6 +104,12 @@ struct ProposeArgs {
   int lds_main;            // max(2 * lds_x_half, lds_tt): T^T overlays X
   PropScalars* scalars;    // device scratch, n_chains * n_steps records
   int dbg;                 // diagnostics only (GSM_PROPOSE_DBG): bit0 cheap coefficients, bit1 skip stage 1, bit2 skip stage 2
+};
+
+// fused chain kernel (chain_fused_kernel.hip): step arguments + proposal arguments of the same call
+struct FusedArgs {
+  StepArgs T;
+  ProposeArgs P;
 };
 
 // scratch + factor table of the Cholesky proposal generator (cholesky_kernel.hip)
@@ -121,11 +133,19 @@ hipError_t launch_cholesky_upper(double* A, int n, int ld, double jitter, int* d
 hipError_t launch_cov_assemble(int bh, int bw, double res, const gsm_vario& v, const double* lag_table, double* sigma,
                                int ld, hipStream_t st);
 hipError_t launch_step(const StepArgs& a, hipStream_t st);
+hipError_t launch_step_flux(const StepArgs& a, hipStream_t st);
+bool step_flux_supported(const StepArgs& a);
+int debug_read_stamps(unsigned long long* out, int n_chains);
+int debug_read_stamps_fused(unsigned long long* out, int n_chains);
+hipError_t launch_pack_flux_static(const StaticFields& S, double2* sA, double2* sB, double2* sC, hipStream_t st);
 hipError_t launch_init_loss(const StaticFields& S, int n_chains, const void* beds, void* energy, int f32_state,
                             double* loss_sum, double* loss0, hipStream_t st);
 hipError_t launch_pack_static(const StaticFields& S, double2* svx, double2* svy, double2* ds, hipStream_t st);
 hipError_t launch_residual(const StaticFields& S, int n_chains, const double* beds, double* out, hipStream_t st);
 hipError_t launch_propose(const ProposeArgs& a, hipStream_t st);
+hipError_t launch_propose_scalars(const ProposeArgs& a, hipStream_t st);
+hipError_t launch_chain_fused(const FusedArgs& a, hipStream_t st);
+bool fused_supported(const FusedArgs& a);
 int propose_max_tiles_per_wave();
 int propose_max_tiles1_per_wave();
 int propose_waves();

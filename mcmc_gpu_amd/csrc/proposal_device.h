@@ -1,0 +1,378 @@
+// Spectral proposal field of one (chain, step) on one workgroup of NT threads (NT = 512: stand-alone proposal kernel,
+// two workgroups per CU; NT = 1024: inside the fused chain kernel).  See proposal_kernel.hip for the algorithm
+// (reference gstatsMCMC/MCMC.py:742-778, :176-254).  The arithmetic of every field value -- including the order of the
+// two reductions of the standardisation -- does not depend on NT, so both forms produce bit-identical fields.
+#pragma once
+#ifndef PSTAMP
+#define PSTAMP(slot) do {} while (0)
+#endif
+#include "gsm_internal.h"
+#include "device_util.h"
+#include "philox.h"
+#include <math.h>
+
+namespace gsm {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pmagic(uint32_t d) { return (uint32_t)(0xFFFFFFFFu / d) + 1u; }
+
+__device__ __forceinline__ void normals2(uint64_t seed, int64_t step, uint32_t stream, uint32_t idx, double& g1,
+                                         double& g2) {
+  const u32x4 r = philox_draw(seed, step, stream, idx);
+  const double u1 = u01_open0_from(r.x, r.y);
+  const double u2 = u01_from(r.z, r.w);
+  const double rad = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincospi(2.0 * u2, &s, &c);
+  g1 = rad * c;
+  g2 = rad * s;
+}
+
+// 2*pi*fftfreq(n, d=res)[k]
+__device__ __forceinline__ double wavenumber(int k, int n, double res) {
+  const int kk = (k < (n + 1) / 2) ? k : k - n;  // numpy fftfreq ordering (n even: k=n/2 -> -n/2)
+  return ((double)kk / ((double)n * res)) * 2.0 * M_PI;
+}
+
+// Sum over the workgroup of per-tile partials: tile t is reduced by the wave that owns it (fixed lane order, DPP),
+// then the 16 tile slots are added by a fixed DPP tree in every thread.  red: 16 doubles of LDS, not reused before the
+// next barrier.
+template <int NT>
+__device__ __forceinline__ double tiles_sum(const double (&part)[16 / (NT / 64)], int n_tiles, double* red, int tid) {
+  constexpr int NW = NT / 64, MAXT = 16 / NW;
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const double w = dev::wave64_sum(part[j]);
+    const int t = wave + j * NW;
+    if ((tid & 63) == 0) red[t] = (t < n_tiles) ? w : 0.0;   // all 16 slots are written
+  }
+  __syncthreads();
+  return dev::row16_sum(red[tid & 15]);   // fixed tree over the 16 tile slots: the same value in every lane
+}
+
+// sqrt(S(k)) of MCMC.py:227-239, :244
+__device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const PropScalars& sc, int ky, int kx, int bh, int bw) {
+  const double kxv = wavenumber(kx, bw, P.resolution), kyv = wavenumber(ky, bh, P.resolution);
+  const double k = sqrt(kxv * kxv + kyv * kyv) + 1e-10;
+  double Sp;
+  if (P.model == GSM_MODEL_GAUSSIAN) { const double ak = sc.aa * k; Sp = exp(-0.5 * (ak * ak)); }
+  else if (P.model == GSM_MODEL_EXPONENTIAL) { const double ak = sc.aa * k; Sp = exp(-1.5 * log(1.0 + ak * ak)); }
+  else {
+    const double nu = (P.smoothness != 0.0) ? P.smoothness : 1.0;
+    Sp = sc.m_const * exp((-nu - 1.0) * log(sc.m_kappa + 4.0 * M_PI * (k * k)));
+  }
+  return sqrt(Sp);
+}
+
+// DFT folding used below (n even, h = n/2).  With P[k] = X[k] + X[n-k], M[k] = X[k] - X[n-k] (0 < k < h; P = X, M = 0
+// for k in {0, h}):   sum_k X[k] e^{+i t k y} = U[y] + i V[y],  U = sum_{k<=h} P[k] cos(t k y),  V = sum_{k<h} M[k] sin(t k y)
+// and the mirrored output is  U[y] - i V[y]  at n - y.  Only k, y in [0, h] enter the products: 4x fewer flops than the
+// dense complex DFT.  The real (c2r) stage folds the same way in x: field[y][x] = E + O, field[y][bw - x] = E - O.
+// plds: LDS work area of a.lds_main doubles (the four coefficient planes, overlaid by T^T); red: 32 doubles of LDS.
+// out: receives the finished (scaled, masked) field, cell o = y * bw + x (global memory or LDS).
+// Contains workgroup barriers: every thread of the workgroup must call it with the same (uniform) arguments.  On return
+// other waves may still be reading `red`; the planes are free once every wave has returned.
+//
+// TABLDS (fused chain kernel, one workgroup per CU): the DFT operand tables of this block shape are staged in LDS --
+// tabA ([cos | sin] of the block height, 2*KR*NR doubles) must not overlap the planes, tabG (folded c2r table of the
+// block width, 2*Kc*M1 doubles) must not overlap planes, T^T or tabA and may overlap `out` -- so the MFMA loops read
+// both operands from LDS, and the edge-mask loads are issued one phase ahead of their use.  Arithmetic identical to the
+// global-table form.
+
+// after_coeff(): called by every thread once its share of the coefficient phase is done (before the first barrier); it
+// must issue exactly HOOK_VMEM vector-memory instructions --
+// the fused kernel issues the loads of the chain state there, so that they fly during the two MFMA stages without
+// occupying registers during the register-hungry coefficient phase.
+template <int NT, bool TABLDS, int HOOK_VMEM, class Hook>
+__device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& a, const PropScalars& sc, const uint64_t seed,
+                                              const int64_t step, double* plds, double* red, double* tabA, double* tabG, Hook after_coeff,
+                                              double* __restrict__ out) {
+  constexpr int NW = NT / 64, MAXT = 16 / NW;
+  const int SX = a.lds_sx, ST = a.lds_st;
+  double* Pr = plds;                       // 4 planes [KRmax][SX]: P re, P im, M re, M im
+  double* Pi = Pr + a.lds_x_half;
+  double* Mr = Pi + a.lds_x_half;
+  double* Mi = Mr + a.lds_x_half;
+  double* TT = plds;                       // [2 Kc][ST]  -- overlays the planes once stage 1 has consumed them
+  const int lane = tid & 63, wave = tid >> 6;   // tid: threadIdx.x (the fused kernel passes a per-step copy the
+  const gsm_rf_params& P = a.rf;                // compiler cannot hoist thread-dependent values out of its step loop with)
+  const int bh = sc.bh, bw = sc.bw;
+  const int hh = bh / 2, hw = bw / 2;
+  const int ncol = hw + 1, nrow = hh + 1;
+
+  // padded GEMM dimensions (host builds the tables with the same formulas)
+  const int KR = (nrow + 3) & ~3;          // stage-1 K  (ky <= hh)
+  const int NR = (nrow + 15) & ~15;        // stage-1 N  (y  <= hh)
+  const int M1 = (ncol + 15) & ~15;        // stage-1 M  (kx)  = stage-2 N (x <= hw)
+  const int Kc = (ncol + 3) & ~3;          // stage-2 K per half (re | im rows of T^T)
+  const int N1 = (bh + 15) & ~15;          // stage-2 M  (y)
+
+  if (TABLDS) {
+    // DFT operand tables of this block shape: global -> LDS by LDS-DMA (no registers), in flight during the
+    // coefficient phase; whole 1 KiB pieces (128 doubles: the table sizes are multiples of 128 doubles), piece c by
+    // wave c mod NW.  The barrier after the coefficient phase drains them.
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const double* gA = a.tables + sc.fy_off;
+    for (int c = wv; c < (2 * KR * NR) / 128; c += NW)
+      __builtin_amdgcn_global_load_lds(gA + c * 128 + 2 * lane, (__attribute__((address_space(3))) void*)(tabA + c * 128), 16, 0, 0);
+    const double* gG = a.tables + sc.g_off;
+    for (int c = wv; c < (2 * Kc * M1) / 128; c += NW)
+      __builtin_amdgcn_global_load_lds(gG + c * 128 + 2 * lane, (__attribute__((address_space(3))) void*)(tabG + c * 128), 16, 0, 0);
+  }
+
+  // ---- folded Hermitian half-plane coefficients -> LDS -------------------------------------------
+  // one work item per (ky <= hh, kx): rows ky and bh-ky share the spectral amplitude, and on the two self-conjugate
+  // columns they are a conjugate pair built from the same two draws.
+  {
+    const int npad = KR * M1;
+    const uint32_t m_m1 = pmagic((uint32_t)M1);
+    for (int i = tid; i < npad; i += NT) {
+      const int ky = (int)__umulhi((uint32_t)i, m_m1);
+      const int kx = i - ky * M1;
+      if (ky >= nrow || kx >= ncol) {
+        const int o = ky * SX + kx;
+        Pr[o] = 0.0; Pi[o] = 0.0; Mr[o] = 0.0; Mi[o] = 0.0;
+      }
+    }
+    const int nitem = nrow * ncol;
+    const uint32_t m_nc = pmagic((uint32_t)ncol);
+    for (int i = tid; i < nitem && !(a.dbg & 32); i += NT) {
+      const int ky = (int)__umulhi((uint32_t)i, m_nc);
+      const int kx = i - ky * ncol;
+      const int kyc = bh - ky;
+      const bool paired = (ky != 0) && (ky != hh);
+      double amp, g1, g2, h1 = 0.0, h2 = 0.0;
+      if (a.dbg & 1) { amp = 1.0; g1 = ky; g2 = kx; h1 = 1.0; h2 = 2.0; }
+      else {
+        amp = spectral_amp(P, sc, ky, kx, bh, bw);
+        normals2(seed, step, kStreamSpectrum, (uint32_t)(ky * ncol + kx), g1, g2);
+        if (paired) normals2(seed, step, kStreamSpectrum, (uint32_t)(kyc * ncol + kx), h1, h2);
+      }
+      double ar, ai, br = 0.0, bi = 0.0;   // X[ky], X[bh - ky]
+      if (kx > 0 && kx < hw) {
+        ar = amp * (g1 * M_SQRT1_2); ai = amp * (g2 * M_SQRT1_2);
+        if (paired) { br = amp * (h1 * M_SQRT1_2); bi = amp * (h2 * M_SQRT1_2); }
+      } else if (paired) {
+        ar = amp * (0.5 * (g1 + h1)); ai = amp * (0.5 * (g2 - h2));
+        br = amp * (0.5 * (h1 + g1)); bi = amp * (0.5 * (h2 - g2));
+      } else {
+        ar = amp * (0.5 * (g1 + g1)); ai = amp * (0.5 * (g2 - g2));
+      }
+      const int o = ky * SX + kx;
+      Pr[o] = ar + br; Pi[o] = ai + bi;
+      Mr[o] = paired ? ar - br : 0.0;
+      Mi[o] = paired ? ai - bi : 0.0;
+    }
+  }
+  after_coeff();
+  PSTAMP(10);
+  if (TABLDS) {
+    // The table LDS-DMAs are older than the HOOK_VMEM vector-memory instructions the hook has just issued: wait for
+    // everything but those (vmcnt counts in order), and for this wave's LDS writes; then a bare barrier.
+    // __syncthreads() would wait vmcnt(0) here, i.e. for the hook's HBM loads.
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(HOOK_VMEM) : "memory");
+  } else {
+    __syncthreads();
+  }
+  PSTAMP(11);
+
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  // ---- stage 1 (MFMA): U = P^T C, V = M^T S on ky, y in [0, hh] -----------------------------------
+  // results wait in registers until every wave has finished reading the planes, then overwrite them as T^T
+  v4f64 ur[MAXT], ui[MAXT], vr[MAXT], vi[MAXT];
+  const int n_mt = M1 >> 4, n_nt = NR >> 4;
+  const int n_t1 = n_mt * n_nt;
+  {
+    const double* __restrict__ FC = a.tables + sc.fy_off;      // [KR][NR]
+    const double* __restrict__ FS = FC + KR * NR;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      v4f64 aur = {0.0, 0.0, 0.0, 0.0}, aui = aur, avr = aur, avi = aur;
+      const int t = wave + j * NW;
+      if (t < n_t1 && !(a.dbg & 2)) {
+        const int mt = t % n_mt, nt = t / n_mt;
+        const int ao = l4 * SX + 16 * mt + l15;
+        const double* fc_p = FC + l4 * NR + 16 * nt + l15;
+        const double* fs_p = FS + l4 * NR + 16 * nt + l15;
+#pragma unroll 2
+        for (int k0 = 0; k0 < KR; k0 += 4) {
+          double bc, bs;
+          if (TABLDS) {
+            const int bo = (l4 + k0) * NR + 16 * nt + l15;
+            bc = tabA[bo]; bs = tabA[KR * NR + bo];
+          } else {
+            bc = fc_p[k0 * NR]; bs = fs_p[k0 * NR];
+          }
+          const int o = ao + k0 * SX;
+          aur = __builtin_amdgcn_mfma_f64_16x16x4f64(Pr[o], bc, aur, 0, 0, 0);
+          aui = __builtin_amdgcn_mfma_f64_16x16x4f64(Pi[o], bc, aui, 0, 0, 0);
+          avr = __builtin_amdgcn_mfma_f64_16x16x4f64(Mr[o], bs, avr, 0, 0, 0);
+          avi = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[o], bs, avi, 0, 0, 0);
+        }
+      }
+      ur[j] = aur; ui[j] = aui; vr[j] = avr; vi[j] = avi;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int t = wave + j * NW;
+    if (t < n_t1) {
+      const int mt = t % n_mt, nt = t / n_mt;
+      const int y = 16 * nt + l15;
+      if (y <= hh) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kx = 16 * mt + l4 + 4 * q;
+          if (kx < Kc) {
+            TT[kx * ST + y] = ur[j][q] - vi[j][q];
+            TT[(Kc + kx) * ST + y] = ui[j][q] + vr[j][q];
+            if (y > 0 && y < hh) {
+              TT[kx * ST + (bh - y)] = ur[j][q] + vi[j][q];
+              TT[(Kc + kx) * ST + (bh - y)] = ui[j][q] - vr[j][q];
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  PSTAMP(12);
+  // ---- stage 2 (MFMA): E = Tr^T Gc, O = Ti^T Gs on x in [0, hw]; results stay in registers -----------
+  v4f64 fe[MAXT], fo[MAXT];
+  const int n_mt2 = N1 >> 4, n_nt2 = M1 >> 4;
+  const int n_t2 = n_mt2 * n_nt2;
+  {
+    const double* __restrict__ GC = a.tables + sc.g_off;       // [Kc][M1]
+    const double* __restrict__ GS = GC + Kc * M1;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      v4f64 ae = {0.0, 0.0, 0.0, 0.0}, ao = ae;
+      const int t = wave + j * NW;
+      if (t < n_t2 && !(a.dbg & 4)) {
+        const int mt = t % n_mt2, nt = t / n_mt2;
+        const double* a_p = TT + l4 * ST + 16 * mt + l15;
+        const double* gc_p = GC + l4 * M1 + 16 * nt + l15;
+        const double* gs_p = GS + l4 * M1 + 16 * nt + l15;
+#pragma unroll 2
+        for (int k0 = 0; k0 < Kc; k0 += 4) {
+          double gc, gs;
+          if (TABLDS) {
+            const int bo = (l4 + k0) * M1 + 16 * nt + l15;
+            gc = tabG[bo]; gs = tabG[Kc * M1 + bo];
+          } else {
+            gc = gc_p[k0 * M1]; gs = gs_p[k0 * M1];
+          }
+          ae = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p[k0 * ST], gc, ae, 0, 0, 0);
+          ao = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p[(Kc + k0) * ST], gs, ao, 0, 0, 0);
+        }
+      }
+      fe[j] = ae; fo[j] = ao;
+    }
+  }
+
+  PSTAMP(13);
+  double mreg[MAXT][8];   // TABLDS: edge-mask values of the thread's cells, in flight during stage 2 and the reductions
+  if (TABLDS) {
+    const dev::rsrc_t r_mask = dev::make_rsrc(a.B.masks + sc.mask_off, (uint32_t)(bh * bw) * 8u);
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int t = wave + j * NW;
+      const int mt = t % n_mt2, nt = t / n_mt2;
+      const int x = 16 * nt + l15;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int y = 16 * mt + l4 + 4 * q;
+        const bool ok = (t < n_t2) && (y < bh) && (x <= hw);
+        mreg[j][2 * q] = dev::ld_f64<0>(r_mask, ok ? (uint32_t)(y * bw + x) * 8u : dev::kOOB);
+        mreg[j][2 * q + 1] = dev::ld_f64<0>(r_mask, (ok && x > 0 && x < hw) ? (uint32_t)(y * bw + bw - x) * 8u : dev::kOOB);
+      }
+    }
+  }
+  // ---- standardise (MCMC.py:248) on the register-resident field ---------------------------------
+  // lane holds, per (tile j, reg q): v1 = field[y][x] = E + O and, for 0 < x < hw, v2 = field[y][bw - x] = E - O
+  const int ncell = bh * bw;
+  const double inv_n = 1.0 / (double)ncell;
+  double part[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int t = wave + j * NW;
+    const int mt = t % n_mt2, nt = t / n_mt2;
+    const int x = 16 * nt + l15;
+    double p = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int y = 16 * mt + l4 + 4 * q;
+      const bool ok = (t < n_t2) && (y < bh) && (x <= hw);
+      const bool two = ok && (x > 0) && (x < hw);
+      const double e = fe[j][q], o = fo[j][q];
+      const double v1 = ok ? (e + o) * inv_n : 0.0;
+      const double v2 = two ? (e - o) * inv_n : 0.0;
+      fe[j][q] = v1; fo[j][q] = v2;
+      p += v1 + v2;
+    }
+    part[j] = p;
+  }
+  const double mean = tiles_sum<NT>(part, n_t2, red, tid) * inv_n;
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int t = wave + j * NW;
+    const int mt = t % n_mt2, nt = t / n_mt2;
+    const int x = 16 * nt + l15;
+    double p = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int y = 16 * mt + l4 + 4 * q;
+      const bool ok = (t < n_t2) && (y < bh) && (x <= hw);
+      if (ok) { const double d = fe[j][q] - mean; p += d * d; }
+      if (ok && x > 0 && x < hw) { const double d = fo[j][q] - mean; p += d * d; }
+    }
+    part[j] = p;
+  }
+  const double sd = sqrt(tiles_sum<NT>(part, n_t2, red + 16, tid) * inv_n);
+  const double gain = sc.scale / (sd + 1e-12);
+
+  PSTAMP(14);
+  // ---- scale, nugget (MCMC.py:251), edge mask (MCMC.py:778), store ------------------------------
+  // out = (t + n * sqrt(nug)) * mask with t = (field - mean) * gain.  Without a nugget (nugget_max == 0: n * 0 adds
+  // nothing) the finished value is stored directly; with one, t is stored first and a second pass over cell pairs adds
+  // the nugget normals (one Philox block per pair) and applies the mask -- the same operations in the same order.
+  const double* __restrict__ mask = a.B.masks + sc.mask_off;
+  const bool with_nugget = (P.nugget_max > 0.0);
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int t = wave + j * NW;
+    const int mt = t % n_mt2, nt = t / n_mt2;
+    const int x = 16 * nt + l15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int y = 16 * mt + l4 + 4 * q;
+      if ((t < n_t2) && (y < bh) && (x <= hw) && !(a.dbg & 8)) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          if (half == 1 && !(x > 0 && x < hw)) continue;
+          const int o = y * bw + (half ? bw - x : x);
+          const double v = ((half ? fo[j][q] : fe[j][q]) - mean) * gain;
+          out[o] = with_nugget ? v : v * (TABLDS ? mreg[j][2 * q + half] : mask[o]);
+        }
+      }
+    }
+  }
+  if (with_nugget) {
+    const double sq_nug = sqrt(sc.nug);
+    __syncthreads();
+    for (int pr = tid; 2 * pr < ncell; pr += NT) {
+      double n1, n2;
+      normals2(seed, step, kStreamNugget, (uint32_t)pr, n1, n2);
+      const int o = 2 * pr;
+      out[o] = (out[o] + n1 * sq_nug) * mask[o];
+      out[o + 1] = (out[o + 1] + n2 * sq_nug) * mask[o + 1];
+    }
+  }
+}
+
+}  // namespace gsm

@@ -357,7 +357,9 @@ hipError_t launch_step(const StepArgs& a, hipStream_t st) {
   // (window cells <= KMAX * NT and tile cells <= (KMAX + 1) * NT)
   const int max_win = std::max(a.B.max_bh * a.B.max_bw, a.tile_cap - 1024);
   static int variant = -1;
-  if (variant < 0) { const char* v = getenv("GSM_STEP_VARIANT"); variant = v ? atoi(v) : 1; }
+  if (variant < 0) { const char* v = getenv("GSM_STEP_VARIANT"); variant = v ? atoi(v) : 3; }
+  // default: the flux-tile kernel (step_flux_kernel.hip); blocks beyond its two LDS tiles fall back to the bed-tile form
+  if (variant == 3 && step_flux_supported(a)) return launch_step_flux(a, st);
   if (a.f32_state) {
     if (max_win <= 1024 * 7) return launch_step_t<float, 1024, 7, 8>(a, st);
     if (max_win <= 1024 * 12) return launch_step_t<float, 1024, 12, 4>(a, st);
