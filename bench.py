@@ -5,7 +5,8 @@
 
 Workload (BASELINE.json configs[1]): 256x256 synthetic grid, 1024 chains per GPU, fp64,
 Matern(0.9125) spectral proposals, blocks 50-80 cells, sigma_mc = 5, Philox draws generated on the device.
-One bench "step" = `--inner` Metropolis steps of every chain (one gsm_run_philox call).  Weak scaling: every
+One bench "step" = `--inner` Metropolis steps of every chain = one gsm_run_philox call = one launch of the fused chain
+kernel (proposal + Metropolis step per chain-step inside it; GSM_FUSED=0 selects the older two-kernel pipeline).  Weak scaling: every
 rank runs its own 1024 chains (different seeds), no collective inside the step loop, one all-gather of the
 per-chain caches and an all-reduce of the posterior-mean field at the end of the timed region.
 
@@ -33,17 +34,20 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak
 
 
-def pmc_traffic(H, n_chains, batch):
-    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of scripts/pmc_run.py, calibrated on a stream copy
-    of known size with the same 8-byte-per-lane access shape).  None when no measurement matches this config."""
+def pmc_traffic(H, n_chains, steps_per_launch):
+    """HBM-side bytes per launch of the fused chain kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of scripts/pmc_fused.py,
+    calibrated on a stream copy of known size, MI355X_MICROARCH.md HBM section), plus the SQ counters of the same
+    workload.  (None, None) when no measurement matches this config."""
     try:
         d = json.load(open(ROOT / "profiles" / "pmc_traffic.json"))
-        if (d["grid"], d["chains"], d["steps_per_launch"]) == (H, n_chains, batch):
-            return d["step_kernel_hbm_bytes_per_launch"]
+        if (d["grid"], d["chains"], d["steps_per_launch"]) == (H, n_chains, steps_per_launch):
+            sq = {k: d[k] for k in ("valu_busy_frac_per_simd", "mfma_busy_frac_per_simd",
+                                    "valu_wave_instructions_per_chain_step", "mfma_instructions_per_chain_step") if k in d}
+            return d["hbm_bytes_per_launch"], sq
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def algorithmic_bytes(blocks, accept, H, W, state_bytes=8):
@@ -193,10 +197,11 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
 
-    # the two kernels co-run on two streams in the timed region, which stretches each one's duration; time one launch of
-    # each ALONE as well (outside the timed region) so the roofline can be read both ways
+    # two-kernel pipeline only (GSM_FUSED=0): the kernels co-run on two streams in the timed region, which stretches each
+    # one's duration; time one launch of each ALONE as well (outside the timed region) so the roofline can be read both ways
     iso = None
-    if args.generator == "spectral":
+    fused = args.generator == "spectral" and os.environ.get("GSM_FUSED", "1") != "0"
+    if args.generator == "spectral" and not fused:
         import ctypes as C
         from mcmc_gpu_amd.engine import _ptr
         nrec = n_local * batch
@@ -232,13 +237,22 @@ def main():
         bytes_per_launch = bytes_total / max(n_step_l, 1)
         step_ms = t_step / max(n_step_l, 1); prop_ms = t_prop / max(n_prop_l, 1)
         dom = "step_kernel" if t_step >= t_prop else "propose_kernel"
-        dom_ms = step_ms if dom == "step_kernel" else prop_ms
+        if fused:
+            dom = "chain_fused_kernel"
+        dom_ms = prop_ms if dom == "propose_kernel" else step_ms
         achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic, sq = pmc_traffic(H, n_local, inner) if fused else (None, None)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(H, n_local, batch), "kernel": dom,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
                 "algorithmic_bytes_per_chain_step": bytes_total / (n_local * n_timed),
-                "bytes_per_launch": bytes_per_launch,
-                "step_kernel_ms": step_ms, "propose_kernel_ms": prop_ms, "launches": n_step_l}
+                "bytes_per_launch": bytes_per_launch, "kernel_ms": dom_ms, "launches": n_step_l}
+        if fused:
+            # what actually limits the fused kernel: fp64 VALU issue (Philox + Box-Muller + spectral amplitude + index
+            # math) with the fp64 matrix pipe on the same datapath -- rocprofv3 SQ counters of the same workload
+            if sq:
+                roof["issue_limits"] = sq
+        else:
+            roof["step_kernel_ms"] = step_ms; roof["propose_kernel_ms"] = prop_ms
         if iso is not None:
             for k in ("step_kernel", "propose_kernel"):
                 iso[k + "_frac"] = iso["bytes_per_launch"] / (iso[k + "_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -264,7 +278,8 @@ def main():
                                       if args.generator == "spectral" else
                                       f"precomputed-Cholesky (Matern 0.9125, {args.classes} range classes) proposals, "
                                       "blocks 50-80, sigma_mc 5 (BASELINE configs[3])"),
-                       "chains_total": n_total, "mh_steps_per_bench_step": inner, "steps_per_launch": batch},
+                       "chains_total": n_total, "mh_steps_per_bench_step": inner,
+                       "steps_per_launch": inner if fused else batch},
             "accept_rate": h_acc_rate, "final_loss_mean": float(h_loss.mean()),
             "roofline": roof,
         }

@@ -212,8 +212,17 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       asm volatile("" : "+v"(acc_old));
       __builtin_amdgcn_sched_barrier(0);
     }
+    // (dhdt_mc, smb) of the window cells: issued before the barrier, in flight across it
+    double2 C2[KT];
+    asm volatile("" : "+v"(ptid));
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      int i, lr, lc; uint32_t g; bool valid, inwin;
+      cell(k, i, lr, lc, g, valid, inwin);
+      C2[k] = ld_f64x2(r_sC, inwin ? g * 16u : kOOB);
+    }
     STAMP(4);
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS tiles complete; the loads above stay in flight
     STAMP(5);
 
     // ---- D: residual stencil on the flux tiles ---------------------------------------------------------
@@ -221,13 +230,6 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     double acc_new = 0.0;
     asm volatile("" : "+v"(ptid));
     {
-      double2 C2[KT];   // (dhdt_mc, smb) of the window cells
-#pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        int i, lr, lc; uint32_t g; bool valid, inwin;
-        cell(k, i, lr, lc, g, valid, inwin);
-        C2[k] = ld_f64x2(r_sC, inwin ? g * 16u : kOOB);
-      }
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         int i, lr, lc; uint32_t g; bool valid, inwin;

@@ -177,24 +177,34 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
     __syncthreads();
   }
   PSTAMP(11);
+  // Mean of the field (MCMC.py:248 subtracts it): every non-DC term of the inverse DFT sums to zero over the block, so
+  // mean = X[0][0] / (bh bw) with X[0][0] = Pr[0] (real: its own conjugate partner).  Read before T^T overlays the plane.
+  const double dc = Pr[0];
 
   const int l15 = lane & 15, l4 = lane >> 4;
 
   // ---- stage 1 (MFMA): U = P^T C, V = M^T S on ky, y in [0, hh] -----------------------------------
-  // results wait in registers until every wave has finished reading the planes, then overwrite them as T^T
-  v4f64 ur[MAXT], ui[MAXT], vr[MAXT], vi[MAXT];
+  // Work unit = half an output tile: half 0 accumulates (Ur, Vi) = (Pr C, Mi S), which is all the real part of T^T
+  // needs; half 1 accumulates (Ui, Vr) = (Pi C, Mr S) for the imaginary part.  Unit u goes to wave u mod NW, so the
+  // (up to 18) units spread over all waves and SIMDs.  Results wait in registers until every wave has finished reading
+  // the planes, then overwrite them as T^T.
+  constexpr int UPW = 32 / NW;                 // units per wave: 2 halves x (at most 16 tiles) / NW
+  v4f64 uc[UPW], us[UPW];                      // cos-product and sin-product accumulators of the unit
   const int n_mt = M1 >> 4, n_nt = NR >> 4;
   const int n_t1 = n_mt * n_nt;
   {
     const double* __restrict__ FC = a.tables + sc.fy_off;      // [KR][NR]
     const double* __restrict__ FS = FC + KR * NR;
 #pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-      v4f64 aur = {0.0, 0.0, 0.0, 0.0}, aui = aur, avr = aur, avi = aur;
-      const int t = wave + j * NW;
+    for (int j = 0; j < UPW; ++j) {
+      v4f64 ac = {0.0, 0.0, 0.0, 0.0}, as = ac;
+      const int u = wave + j * NW;
+      const int t = u >> 1;
       if (t < n_t1 && !(a.dbg & 2)) {
         const int mt = t % n_mt, nt = t / n_mt;
         const int ao = l4 * SX + 16 * mt + l15;
+        const double* __restrict__ Ac = (u & 1) ? Pi : Pr;
+        const double* __restrict__ As = (u & 1) ? Mr : Mi;
         const double* fc_p = FC + l4 * NR + 16 * nt + l15;
         const double* fs_p = FS + l4 * NR + 16 * nt + l15;
 #pragma unroll 2
@@ -207,33 +217,29 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
             bc = fc_p[k0 * NR]; bs = fs_p[k0 * NR];
           }
           const int o = ao + k0 * SX;
-          aur = __builtin_amdgcn_mfma_f64_16x16x4f64(Pr[o], bc, aur, 0, 0, 0);
-          aui = __builtin_amdgcn_mfma_f64_16x16x4f64(Pi[o], bc, aui, 0, 0, 0);
-          avr = __builtin_amdgcn_mfma_f64_16x16x4f64(Mr[o], bs, avr, 0, 0, 0);
-          avi = __builtin_amdgcn_mfma_f64_16x16x4f64(Mi[o], bs, avi, 0, 0, 0);
+          ac = __builtin_amdgcn_mfma_f64_16x16x4f64(Ac[o], bc, ac, 0, 0, 0);
+          as = __builtin_amdgcn_mfma_f64_16x16x4f64(As[o], bs, as, 0, 0, 0);
         }
       }
-      ur[j] = aur; ui[j] = aui; vr[j] = avr; vi[j] = avi;
+      uc[j] = ac; us[j] = as;
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < MAXT; ++j) {
-    const int t = wave + j * NW;
+  for (int j = 0; j < UPW; ++j) {
+    const int u = wave + j * NW;
+    const int t = u >> 1;
     if (t < n_t1) {
       const int mt = t % n_mt, nt = t / n_mt;
       const int y = 16 * nt + l15;
       if (y <= hh) {
+        double* __restrict__ Th = TT + ((u & 1) ? Kc * ST : 0);   // real rows, then imaginary rows
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int kx = 16 * mt + l4 + 4 * q;
           if (kx < Kc) {
-            TT[kx * ST + y] = ur[j][q] - vi[j][q];
-            TT[(Kc + kx) * ST + y] = ui[j][q] + vr[j][q];
-            if (y > 0 && y < hh) {
-              TT[kx * ST + (bh - y)] = ur[j][q] + vi[j][q];
-              TT[(Kc + kx) * ST + (bh - y)] = ui[j][q] - vr[j][q];
-            }
+            Th[kx * ST + y] = (u & 1) ? uc[j][q] + us[j][q] : uc[j][q] - us[j][q];
+            if (y > 0 && y < hh) Th[kx * ST + (bh - y)] = (u & 1) ? uc[j][q] - us[j][q] : uc[j][q] + us[j][q];
           }
         }
       }
@@ -303,7 +309,6 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
     const int t = wave + j * NW;
     const int mt = t % n_mt2, nt = t / n_mt2;
     const int x = 16 * nt + l15;
-    double p = 0.0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int y = 16 * mt + l4 + 4 * q;
@@ -313,11 +318,9 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
       const double v1 = ok ? (e + o) * inv_n : 0.0;
       const double v2 = two ? (e - o) * inv_n : 0.0;
       fe[j][q] = v1; fo[j][q] = v2;
-      p += v1 + v2;
     }
-    part[j] = p;
   }
-  const double mean = tiles_sum<NT>(part, n_t2, red, tid) * inv_n;
+  const double mean = dc * inv_n;
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
     const int t = wave + j * NW;
@@ -333,7 +336,7 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
     }
     part[j] = p;
   }
-  const double sd = sqrt(tiles_sum<NT>(part, n_t2, red + 16, tid) * inv_n);
+  const double sd = sqrt(tiles_sum<NT>(part, n_t2, red, tid) * inv_n);
   const double gain = sc.scale / (sd + 1e-12);
 
   PSTAMP(14);

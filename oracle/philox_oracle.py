@@ -123,8 +123,13 @@ def proposal(seed, step, rf, pairs, masks, centres, W, resolution):
     for kx in (0, bw // 2):
         X[:, kx] = amp[:, kx] * (0.5 * (g1[:, kx] + g1[kyc, kx])) + 1j * (amp[:, kx] * (0.5 * (g2[:, kx] - g2[kyc, kx])))
     fld = np.fft.irfft2(X, s=(bh, bw))
-    raw_mean, raw_std = float(np.mean(fld)), float(np.std(fld))
-    fld = (fld - np.mean(fld)) / (np.std(fld) + 1e-12)
+    # standardisation (MCMC.py:248).  The device takes the mean from the DC coefficient -- every other term of the inverse
+    # DFT sums to zero over the block, so mean(fld) == X[0, 0].real / (bh * bw) up to rounding -- and the population std
+    # as sqrt(mean((fld - mean)^2)) like numpy.
+    mean = float(X[0, 0].real) / (bh * bw)
+    raw_mean = mean
+    raw_std = float(np.sqrt(np.mean((fld - mean) ** 2)))
+    fld = (fld - mean) / (raw_std + 1e-12)
     fld = fld * scale
     if rf.nugget_max > 0.0:
         o = np.arange(bh * bw)

@@ -1,39 +1,56 @@
-"""profiles/pmc_traffic.json from two rocprofv3 --pmc passes of scripts/pmc_run.py (FETCH_SIZE, WRITE_SIZE).
+"""profiles/pmc_traffic.json from rocprofv3 --pmc passes of scripts/pmc_fused.py (FETCH_SIZE, WRITE_SIZE in separate
+passes; optionally a third directory with SQ counters).
 
 Correction per MI355X_MICROARCH.md (HBM section): the counters are in KiB; FETCH_SIZE under-reports wide coalesced
-reads on gfx950, so it is calibrated on gsm::stream_copy_kernel (same 8-byte-per-lane access shape as the step kernel,
-exactly 512 MiB read and 512 MiB written); WRITE_SIZE is checked on the same kernel."""
+reads on gfx950, so it is calibrated on gsm::stream_copy_kernel (8 bytes per lane, exactly 512 MiB read and 512 MiB
+written in the same run); WRITE_SIZE is checked on the same kernel."""
 import csv, glob, json, sys
 fetch_dir, write_dir, log, out = sys.argv[1:5]
-def mean_per_kernel(d, counter):
+sq_dirs = sys.argv[5:]
+def mean_per_kernel(dirs, counter):
     acc = {}
-    for f in glob.glob(f'{d}/**/*_counter_collection.csv', recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] == counter:
-                acc.setdefault(r['Kernel_Name'].split('(')[0], []).append(float(r['Counter_Value']))
+    for d in dirs:
+        for f in glob.glob(f'{d}/**/*_counter_collection.csv', recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r['Counter_Name'] == counter:
+                    acc.setdefault(r['Kernel_Name'].split('(')[0], []).append(float(r['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in acc.items()}
-F, Wr = mean_per_kernel(fetch_dir, 'FETCH_SIZE'), mean_per_kernel(write_dir, 'WRITE_SIZE')
+F, Wr = mean_per_kernel([fetch_dir], 'FETCH_SIZE'), mean_per_kernel([write_dir], 'WRITE_SIZE')
 work = [json.loads(l) for l in open(log) if l.startswith('{')]
 plane = work[0]['plane_bytes']
 copy = [k for k in F if 'stream_copy' in k][0]
-step = [k for k in F if 'step_kernel' in k][0]
-prop = [k for k in F if k.endswith('propose_kernel')][0]
+fused = [k for k in F if 'chain_fused_kernel' in k][0]
 f_fetch = plane / (F[copy] * 1024)
 f_write = plane / (Wr[copy] * 1024)
-alg = sum(w['algorithmic_bytes_step_launch'] for w in work) / len(work)
+alg = sum(w['algorithmic_bytes_launch'] for w in work) / len(work)
 res = {
-    "grid": 256, "chains": 1024, "steps_per_launch": 32,
-    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over scripts/pmc_run.py; KiB units; "
+    "grid": 256, "chains": 1024, "steps_per_launch": work[0]['steps'],
+    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over scripts/pmc_fused.py; KiB units; "
               "read side multiplied by the factor measured on gsm::stream_copy_kernel (known 512 MiB)",
     "calibration": {"kernel": copy, "known_bytes": plane, "FETCH_SIZE_KiB": F[copy], "WRITE_SIZE_KiB": Wr[copy],
                     "fetch_factor": f_fetch, "write_factor": f_write},
-    "step_kernel": step,
-    "step_kernel_FETCH_SIZE_KiB": F[step], "step_kernel_WRITE_SIZE_KiB": Wr[step],
-    "step_kernel_hbm_bytes_per_launch": (F[step] * f_fetch + Wr[step] * f_write) * 1024,
-    "step_kernel_algorithmic_bytes_per_launch": alg,
-    "propose_kernel_hbm_bytes_per_launch": (F[prop] * f_fetch + Wr[prop] * f_write) * 1024,
-    "note": "the read side counts L2 -> fabric requests, Infinity-Cache hits included: re-fetches of the shared static "
-            "fields evicted from the 4 MiB L2 by the per-chain streams show up here although they rarely reach HBM",
+    "kernel": fused,
+    "FETCH_SIZE_KiB": F[fused], "WRITE_SIZE_KiB": Wr[fused],
+    "hbm_bytes_per_launch": (F[fused] * f_fetch + Wr[fused] * f_write) * 1024,
+    "algorithmic_bytes_per_launch": alg,
+    "note": "the read side counts L2 -> fabric requests, Infinity-Cache hits included",
 }
+if sq_dirs:
+    sq = {}
+    for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+              "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_SALU",
+              "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+        m = mean_per_kernel(sq_dirs, c)
+        if fused in m:
+            sq[c] = m[fused]
+    res["sq_counters_per_launch"] = sq
+    if "SQ_WAVE_CYCLES" in sq and "SQ_ACTIVE_INST_VALU" in sq:
+        waves_per_simd = 4   # one 1024-thread workgroup per CU
+        # SQ_WAVE_CYCLES and SQ_ACTIVE_INST_* count quad-cycles per wave; a SIMD executes one VALU instruction at a time
+        res["valu_busy_frac_per_simd"] = waves_per_simd * sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]
+        res["mfma_busy_frac_per_simd"] = sq.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (sq["SQ_WAVE_CYCLES"] * 4 / waves_per_simd)
+        chain_steps = res["chains"] * res["steps_per_launch"]
+        res["valu_wave_instructions_per_chain_step"] = sq.get("SQ_INSTS_VALU", 0.0) / chain_steps
+        res["mfma_instructions_per_chain_step"] = sq.get("SQ_INSTS_MFMA", 0.0) / chain_steps
 json.dump(res, open(out, 'w'), indent=1)
 print(json.dumps(res, indent=1))
