@@ -26,6 +26,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 namespace gsm {
 
@@ -127,16 +128,28 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     if ((hr0 < pr1) && (pr0 < hr1) && (hc0 < pc1) && (pc0 < hc1)) __syncthreads();
 
     STAMP(0);
-    int ptid = tid;   // re-laundered at each phase so that the geometry is recomputed, not kept live across phases
+    // Geometry of the thread's tile cells t, t + 1024, ...: the first one by (magic) division, the others from per-k
+    // uniform quotients/remainders (scalar unit) and one conditional wrap -- no per-cell multiplies.  lr0/lc0/g0 are
+    // laundered per phase so that the few derived values are recomputed instead of being kept live across phases.
+    int lr0 = (int)__umulhi((uint32_t)tid, m_tw);
+    int lc0 = tid - lr0 * tw;
+    uint32_t g0 = (uint32_t)((hr0 + lr0) * W + hc0 + lc0);
+    int ptid = tid;
     asm volatile("" : "+v"(ptid));
     auto cell = [&](int k, int& i, int& lr, int& lc, uint32_t& g, bool& valid, bool& inwin) {
       i = ptid + k * kNT;
       valid = i < ncell;
-      lr = (int)__umulhi((uint32_t)i, m_tw);
-      lc = i - lr * tw;
-      g = (uint32_t)((hr0 + lr) * W + hc0 + lc);
+      const int qk = (int)(((uint64_t)(uint32_t)(k * kNT) * m_tw) >> 32);   // (k * 1024) / tw, uniform
+      const int remk = k * kNT - qk * tw;
+      lc = lc0 + remk;
+      lr = lr0 + qk;
+      const bool wrap = lc >= tw;
+      lc -= wrap ? tw : 0;
+      lr += wrap ? 1 : 0;
+      g = g0 + (uint32_t)(qk * W + remk) + (wrap ? (uint32_t)(W - tw) : 0u);
       inwin = valid && (unsigned)(lr - dr) < (unsigned)wh && (unsigned)(lc - dc) < (unsigned)ww;
     };
+    auto relaunder = [&] { asm volatile("" : "+v"(ptid), "+v"(lr0), "+v"(lc0), "+v"(g0)); };
 
     // ---- P: proposal field -> LDS; P0 (inside, after the coefficient phase): chain state of the window -> registers,
     // in flight during the two MFMA stages ---------------------------------------------------------------------
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     uint32_t upd_bits = 0;
     double acc_old = 0.0;
     int guard = 0;
-    asm volatile("" : "+v"(ptid));
+    relaunder();
     constexpr int KB = (KT > 4) ? 4 : KT;
 #pragma unroll
     for (int kb = 0; kb < KT; kb += KB) {
@@ -214,7 +227,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     }
     // (dhdt_mc, smb) of the window cells: issued before the barrier, in flight across it
     double2 C2[KT];
-    asm volatile("" : "+v"(ptid));
+    relaunder();
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       int i, lr, lc; uint32_t g; bool valid, inwin;
@@ -228,26 +241,37 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     // ---- D: residual stencil on the flux tiles ---------------------------------------------------------
     double e_new[KT];
     double acc_new = 0.0;
-    asm volatile("" : "+v"(ptid));
-    {
+    relaunder();
+    // interior step (a halo ring on all four sides, ~5 steps in 6): no window cell touches a grid border, every
+    // difference is central.  The general form applies np.gradient's one-sided edge rules.
+    const bool interior = (hr0 < r0) && (hr1 > r1) && (hc0 < c0) && (hc1 > c1);
+    auto phase_d = [&](auto interior_tag) {
+      constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         int i, lr, lc; uint32_t g; bool valid, inwin;
         cell(k, i, lr, lc, g, valid, inwin);
-        const int r = hr0 + lr, c = hc0 + lc;
-        const int il = (c == 0) ? i : i - 1, ir = (c == W - 1) ? i : i + 1;
-        const int iu = (r == 0) ? i : i - tw, id = (r == H - 1) ? i : i + tw;
         double e = 0.0;
         if (inwin) {
-          const double ddx = qx[ir] - qx[il];
-          const double ddy = qy[id] - qy[iu];
           double dx, dy;
-          if (FAST_DIV) {
-            dx = (ir - il == 2) ? exact_div(ddx, S.two_res, S.rcp_two_res) : exact_div(ddx, S.res, S.rcp_res);
-            dy = (id - iu == 2 * tw) ? exact_div(ddy, S.two_res, S.rcp_two_res) : exact_div(ddy, S.res, S.rcp_res);
+          if (INTERIOR) {
+            const double ddx = qx[i + 1] - qx[i - 1];
+            const double ddy = qy[i + tw] - qy[i - tw];
+            if (FAST_DIV) { dx = exact_div(ddx, S.two_res, S.rcp_two_res); dy = exact_div(ddy, S.two_res, S.rcp_two_res); }
+            else { dx = ddx / S.two_res; dy = ddy / S.two_res; }
           } else {
-            dx = ddx / ((ir - il == 2) ? S.two_res : S.res);
-            dy = ddy / ((id - iu == 2 * tw) ? S.two_res : S.res);
+            const int r = hr0 + lr, c = hc0 + lc;
+            const int il = (c == 0) ? i : i - 1, ir = (c == W - 1) ? i : i + 1;
+            const int iu = (r == 0) ? i : i - tw, id = (r == H - 1) ? i : i + tw;
+            const double ddx = qx[ir] - qx[il];
+            const double ddy = qy[id] - qy[iu];
+            if (FAST_DIV) {
+              dx = (ir - il == 2) ? exact_div(ddx, S.two_res, S.rcp_two_res) : exact_div(ddx, S.res, S.rcp_res);
+              dy = (id - iu == 2 * tw) ? exact_div(ddy, S.two_res, S.rcp_two_res) : exact_div(ddy, S.res, S.rcp_res);
+            } else {
+              dx = ddx / ((ir - il == 2) ? S.two_res : S.res);
+              dy = ddy / ((id - iu == 2 * tw) ? S.two_res : S.res);
+            }
           }
           const double v = ((dx + dy) + C2[k].x) - C2[k].y;
           if (!isnan(v)) e = v * v;
@@ -257,7 +281,8 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
         acc_new += e;
         if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);
       }
-    }
+    };
+    if (interior) phase_d(std::true_type{}); else phase_d(std::false_type{});
 
     sc_next = unpack_scalars(nxt_dw);
     STAMP(6);
@@ -289,7 +314,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
 
     // ---- E: commit -------------------------------------------------------------------------------------
     if (acc) {
-      asm volatile("" : "+v"(ptid));
+      relaunder();
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         int i, lr, lc; uint32_t g; bool valid, inwin;
