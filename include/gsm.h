@@ -147,15 +147,21 @@ int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, const uint6
                        const gsm_rf_params* rf, int32_t* size_idx, int32_t* centre, double* u,
                        double* fields, int64_t field_stride, double* rf_scalars, void* stream);
 
-/* Philox mode end to end: batches of `batch` steps, proposals of batch k+1 generated on a second
- * stream while batch k is stepped.  Outputs as gsm_run_replay plus blocks [dev, n_chains*n_steps*4]
- * = (row, col, bh, bw) (blocks_cache, MCMC.py:1264).  Scratch for the proposals is owned by the handle.
- * Synchronises the stream before returning.
+/* Philox mode end to end.  Spectral generator: one launch of the fused chain kernel (per chain-step the proposal is
+ * generated and consumed inside one workgroup; nothing but chain state touches HBM; `batch` is not used).  Cholesky
+ * generator, block tables beyond the fused kernel's LDS budget, or GSM_FUSED=0 in the environment: batches of `batch`
+ * steps, proposals of batch k+1 generated on a second stream while batch k is stepped, scratch owned by the handle.
+ * Both forms give bit-identical results.  Outputs as gsm_run_replay plus blocks [dev, n_chains*n_steps*4]
+ * = (row, col, bh, bw) (blocks_cache, MCMC.py:1264).  Synchronises the stream before returning.
  * Replaces: chain_crf.run for a whole shard of chains (MCMC.py:1137-1443) as called from
  * lsc_run_wrapper (largeScaleChain_multiprocessing_GPU.py:194-201). */
 int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int32_t batch, const uint64_t* seeds,
                    const gsm_rf_params* rf, void* beds, void* energy, uint32_t* resampled, double* loss_sum,
                    double* loss, uint8_t* accept, int32_t* blocks, void* stream);
+
+/* Select the launch structure of gsm_run_philox for the spectral generator on this handle: 1 = fused chain kernel
+ * (default), 0 = two-kernel pipeline.  Identical results; kept for A/B measurements and tests. */
+int gsm_set_fused(gsm_handle h, int32_t on);
 
 /* Average duration in milliseconds of the step kernel / the proposal kernel over the launches made
  * by the last gsm_run_philox call, measured with HIP events on the streams the kernels ran on

@@ -50,6 +50,7 @@ struct gsm_context {
   hipEvent_t ev_prop[2] = {nullptr, nullptr}, ev_step[2] = {nullptr, nullptr};
   // timing
   bool timing = false;
+  int use_fused = -1;     // -1: decide from GSM_FUSED at the first gsm_run_philox; 0 / 1: set by gsm_set_fused
   double t_step_ms = 0, t_prop_ms = 0;
   int n_step_launch = 0, n_prop_launch = 0;
 };
@@ -455,6 +456,12 @@ extern "C" int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, 
   return GSM_OK;
 }
 
+extern "C" int gsm_set_fused(gsm_handle h, int32_t on) {
+  if (!h) return GSM_E_ARG;
+  h->use_fused = on ? 1 : 0;
+  return GSM_OK;
+}
+
 extern "C" int gsm_enable_timing(gsm_handle h, int32_t on) {
   if (!h) return GSM_E_ARG;
   h->timing = on != 0;
@@ -487,9 +494,8 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
   // Spectral generator: one fused launch (chain_fused_kernel.hip) -- proposals are generated and consumed on the CU,
   // no field scratch, no second stream.  GSM_FUSED=0 keeps the two-kernel pipeline (also used by the Cholesky generator
   // and by block tables beyond the fused kernel's LDS budget).
-  static int use_fused = -1;
-  if (use_fused < 0) { const char* v = getenv("GSM_FUSED"); use_fused = (v && atoi(v) == 0) ? 0 : 1; }
-  if (use_fused && rf->generator == GSM_GEN_SPECTRAL) {
+  if (h->use_fused < 0) { const char* v = getenv("GSM_FUSED"); h->use_fused = (v && atoi(v) == 0) ? 0 : 1; }
+  if (h->use_fused && rf->generator == GSM_GEN_SPECTRAL) {
     FusedArgs fa{};
     StepArgs& a = fa.T;
     a.S = h->S; a.B = h->B;

@@ -260,6 +260,10 @@ class GsmEngine:
         self._check(self.lib.gsm_last_timing(self.h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
         return dict(step_ms=a.value, step_launches=na.value, proposal_ms=b.value, proposal_launches=nb.value)
 
+    def set_fused(self, on: bool):
+        """Philox mode, spectral generator: fused chain kernel (default) or the two-kernel pipeline (same results)."""
+        self._check(self.lib.gsm_set_fused(self.h, 1 if on else 0))
+
     def run_philox(self, n_steps, step0, seeds, rf, batch=8, out=None, to_host=True):
         """n_steps Metropolis steps for every chain with on-device proposals.
         Returns (loss, accept, blocks): (n_chains, n_steps), (n_chains, n_steps), (n_chains, n_steps, 4)."""
