@@ -17,12 +17,43 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t pmagic(uint32_t d) { return (uint32_t)(0xFFFFFFFFu / d) + 1u; }
 
+// log(x) for positive, finite, normal x (here: uniforms in [2^-53, 1] and spectral-density arguments): the fdlibm
+// e_log.c algorithm (argument reduction to [sqrt(1/2), sqrt(2)), s = f / (2 + f), degree-7 minimax in s^2; error
+// < 1 ulp) without the special-case handling and the double-double arithmetic of the library routine -- about half its
+// instructions.  Horner steps are explicit fmas (this file is built with -ffp-contract=off).
+__device__ __forceinline__ double log_pos(double x) {
+  const uint64_t bits = __builtin_bit_cast(uint64_t, x);
+  int k = (int)(bits >> 52) - 1023;
+  uint64_t mant = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;   // m in [1, 2)
+  if ((bits & 0x000FFFFFFFFFFFFFull) >= 0x6A09E667F3BCDull) {                // m >= sqrt(2): halve
+    mant -= 0x0010000000000000ull;
+    k += 1;
+  }
+  const double f = __builtin_bit_cast(double, mant) - 1.0;
+  // s = f / (2 + f), divisor in [1.7, 2.42): reciprocal estimate, two Newton steps, one residual correction
+  const double d = 2.0 + f;
+  double y = __builtin_amdgcn_rcp(d);
+  y = __fma_rn(__fma_rn(-d, y, 1.0), y, y);
+  y = __fma_rn(__fma_rn(-d, y, 1.0), y, y);
+  double s = f * y;
+  s = __fma_rn(__fma_rn(-s, d, f), y, s);
+  const double z = s * s, w = z * z;
+  const double t1 = w * __fma_rn(w, __fma_rn(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
+                                 3.999999999940941908e-01);
+  const double t2 = z * __fma_rn(w, __fma_rn(w, __fma_rn(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                             2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)k;
+  return dk * 6.93147180369123816490e-01 - ((hfsq - __fma_rn(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+
 __device__ __forceinline__ void normals2(uint64_t seed, int64_t step, uint32_t stream, uint32_t idx, double& g1,
                                          double& g2) {
   const u32x4 r = philox_draw(seed, step, stream, idx);
   const double u1 = u01_open0_from(r.x, r.y);
   const double u2 = u01_from(r.z, r.w);
-  const double rad = sqrt(-2.0 * log(u1));
+  const double rad = sqrt(-2.0 * log_pos(u1));
   double s, c;
   sincospi(2.0 * u2, &s, &c);
   g1 = rad * c;
@@ -58,10 +89,10 @@ __device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const Pro
   const double k = sqrt(kxv * kxv + kyv * kyv) + 1e-10;
   double Sp;
   if (P.model == GSM_MODEL_GAUSSIAN) { const double ak = sc.aa * k; Sp = exp(-0.5 * (ak * ak)); }
-  else if (P.model == GSM_MODEL_EXPONENTIAL) { const double ak = sc.aa * k; Sp = exp(-1.5 * log(1.0 + ak * ak)); }
+  else if (P.model == GSM_MODEL_EXPONENTIAL) { const double ak = sc.aa * k; Sp = exp(-1.5 * log_pos(1.0 + ak * ak)); }
   else {
     const double nu = (P.smoothness != 0.0) ? P.smoothness : 1.0;
-    Sp = sc.m_const * exp((-nu - 1.0) * log(sc.m_kappa + 4.0 * M_PI * (k * k)));
+    Sp = sc.m_const * exp((-nu - 1.0) * log_pos(sc.m_kappa + 4.0 * M_PI * (k * k)));
   }
   return sqrt(Sp);
 }
