@@ -162,6 +162,8 @@ int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int32_t batch, 
 /* Select the launch structure of gsm_run_philox for the spectral generator on this handle: 1 = fused chain kernel
  * (default), 0 = two-kernel pipeline.  Identical results; kept for A/B measurements and tests. */
 int gsm_set_fused(gsm_handle h, int32_t on);
+/* 1 if the last gsm_run_philox call on this handle ran the fused chain kernel, 0 if the two-kernel pipeline. */
+int gsm_last_run_fused(gsm_handle h);
 
 /* Average duration in milliseconds of the step kernel / the proposal kernel over the launches made
  * by the last gsm_run_philox call, measured with HIP events on the streams the kernels ran on

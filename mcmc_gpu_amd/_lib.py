@@ -134,6 +134,7 @@ def load() -> C.CDLL:
     lib.gsm_run_philox.argtypes = [vp, i32, i64, i32, vp, C.POINTER(RfParams), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsm_enable_timing.argtypes = [vp, i32]
     lib.gsm_set_fused.argtypes = [vp, i32]
+    lib.gsm_last_run_fused.argtypes = [vp]
     lib.gsm_last_timing.argtypes = [vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(dbl), C.POINTER(i32)]
     lib.gsm_cov_assemble.argtypes = [vp, i32, i32, dbl, C.POINTER(Vario), vp, vp, i64, vp]
     lib.gsm_cholesky_upper.argtypes = [vp, vp, i32, i64, dbl, vp]

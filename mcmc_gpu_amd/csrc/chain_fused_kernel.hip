@@ -41,8 +41,13 @@ __device__ unsigned long long g_stamps_fused[4096 * 16];
 #define STAMP(slot) do {} while (0)
 #endif
 
+// work area: flux tiles, overlaid by the DFT planes + the [cos|sin] table during the proposal;
+// field tile: overlaid by the c2r table until the field is written
+static int fused_work_len(const FusedArgs& a) { return std::max(std::max(2 * a.T.tile_cap, a.P.lds_main), 4 * a.P.lds_x_half + a.P.tab_max); }
+static int fused_fld_len(const FusedArgs& a) { return std::max(a.T.B.max_bh * a.T.B.max_bw, a.P.tab_max); }
+
 size_t fused_lds_doubles(const FusedArgs& a) {
-  return (size_t)std::max(2 * a.T.tile_cap, a.P.lds_main) + (size_t)a.T.B.max_bh * a.T.B.max_bw + 4 * kNW + 32 + 16;
+  return (size_t)fused_work_len(a) + (size_t)fused_fld_len(a) + 4 * kNW + 32 + 16;
 }
 
 static_assert(sizeof(PropScalars) == 104, "PropScalars layout is unpacked dword by dword below");
@@ -67,11 +72,11 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
   const StepArgs& a = fa.T;
   const ProposeArgs& pa = fa.P;
   extern __shared__ double lds[];
-  const int work_len = max(2 * a.tile_cap, pa.lds_main);
+  const int work_len = fa.work_len;
   double* __restrict__ qx = lds;
   double* __restrict__ qy = lds + a.tile_cap;
   double* __restrict__ fld = lds + work_len;                       // [max_bh * max_bw]
-  double* __restrict__ red = fld + a.B.max_bh * a.B.max_bw;        // [kNW][4]
+  double* __restrict__ red = fld + fa.fld_len;                     // [kNW][4]
   double* __restrict__ red2 = red + 4 * kNW;                       // [32] proposal reductions
 
   const StaticFields& S = a.S;
@@ -373,15 +378,15 @@ static hipError_t launch_fused_t(const FusedArgs& a, hipStream_t st) {
 }
 
 bool fused_supported(const FusedArgs& a) {
-  // LDS homes of the DFT tables: [cos|sin] behind the planes inside the work area, the c2r table in the field tile
-  const int work = std::max(2 * a.T.tile_cap, a.P.lds_main);
-  return step_flux_supported(a.T) && fused_lds_doubles(a) * sizeof(double) <= 160 * 1024 &&
-         a.P.tab_max > 0 && 4 * a.P.lds_x_half + a.P.tab_max <= work && a.P.tab_max <= a.T.B.max_bh * a.T.B.max_bw;
+  return step_flux_supported(a.T) && a.P.tab_max > 0 && fused_lds_doubles(a) * sizeof(double) <= 160 * 1024;
 }
 
 // One launch: propose_scalars_kernel for all steps must have filled a.P.scalars (n_chains x a.P.n_steps records).
-hipError_t launch_chain_fused(const FusedArgs& a, hipStream_t st) {
-  if (!fused_supported(a)) return hipErrorInvalidValue;
+hipError_t launch_chain_fused(const FusedArgs& a_in, hipStream_t st) {
+  if (!fused_supported(a_in)) return hipErrorInvalidValue;
+  FusedArgs a = a_in;
+  a.work_len = fused_work_len(a);
+  a.fld_len = fused_fld_len(a);
   if (a.T.f32_state) {
     if (a.T.tile_cap <= 2 * kNT) return launch_fused_t<float, 2>(a, st);
     if (a.T.tile_cap <= 4 * kNT) return launch_fused_t<float, 4>(a, st);

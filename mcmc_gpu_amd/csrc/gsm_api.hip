@@ -50,6 +50,7 @@ struct gsm_context {
   hipEvent_t ev_prop[2] = {nullptr, nullptr}, ev_step[2] = {nullptr, nullptr};
   // timing
   bool timing = false;
+  int last_fused = 0;     // 1 when the last gsm_run_philox call went through the fused chain kernel
   int use_fused = -1;     // -1: decide from GSM_FUSED at the first gsm_run_philox; 0 / 1: set by gsm_set_fused
   double t_step_ms = 0, t_prop_ms = 0;
   int n_step_launch = 0, n_prop_launch = 0;
@@ -456,6 +457,8 @@ extern "C" int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, 
   return GSM_OK;
 }
 
+extern "C" int gsm_last_run_fused(gsm_handle h) { return h ? h->last_fused : GSM_E_ARG; }
+
 extern "C" int gsm_set_fused(gsm_handle h, int32_t on) {
   if (!h) return GSM_E_ARG;
   h->use_fused = on ? 1 : 0;
@@ -495,6 +498,7 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
   // no field scratch, no second stream.  GSM_FUSED=0 keeps the two-kernel pipeline (also used by the Cholesky generator
   // and by block tables beyond the fused kernel's LDS budget).
   if (h->use_fused < 0) { const char* v = getenv("GSM_FUSED"); h->use_fused = (v && atoi(v) == 0) ? 0 : 1; }
+  h->last_fused = 0;
   if (h->use_fused && rf->generator == GSM_GEN_SPECTRAL) {
     FusedArgs fa{};
     StepArgs& a = fa.T;
@@ -508,7 +512,9 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
     fa.P = make_propose(h, rf, n_steps, step0, seeds);
     fa.P.scalars = h->d_scalars[0];
     // the scalars kernel also writes (size_idx, centre, u) records: give it the scalar-sized scratch of slot 1
+    h->last_fused = 0;
     if (fused_supported(fa)) {
+      h->last_fused = 1;
       const size_t recs1 = (size_t)h->n_chains * n_steps;
       auto& sc = h->scr[1];
       if (sc.recs < recs1 || sc.fields) {

@@ -110,6 +110,7 @@ struct ProposeArgs {
 struct FusedArgs {
   StepArgs T;
   ProposeArgs P;
+  int work_len, fld_len;   // LDS region sizes in doubles, set by launch_chain_fused
 };
 
 // scratch + factor table of the Cholesky proposal generator (cholesky_kernel.hip)

@@ -179,7 +179,10 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
       else {
         amp = spectral_amp(P, sc, ky, kx, bh, bw);
         normals2(seed, step, kStreamSpectrum, (uint32_t)(ky * ncol + kx), g1, g2);
-        if (paired) normals2(seed, step, kStreamSpectrum, (uint32_t)(kyc * ncol + kx), h1, h2);
+        // drawn unconditionally (counter-based: an unused draw costs nothing downstream): one straight-line block for
+        // both Box-Muller evaluations, so their polynomial constants are materialised once and the two chains interleave
+        normals2(seed, step, kStreamSpectrum, (uint32_t)(kyc * ncol + kx), h1, h2);
+        if (!paired) { h1 = 0.0; h2 = 0.0; }
       }
       double ar, ai, br = 0.0, bi = 0.0;   // X[ky], X[bh - ky]
       if (kx > 0 && kx < hw) {

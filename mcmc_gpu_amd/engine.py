@@ -264,6 +264,9 @@ class GsmEngine:
         """Philox mode, spectral generator: fused chain kernel (default) or the two-kernel pipeline (same results)."""
         self._check(self.lib.gsm_set_fused(self.h, 1 if on else 0))
 
+    def last_run_fused(self) -> bool:
+        return bool(self.lib.gsm_last_run_fused(self.h))
+
     def run_philox(self, n_steps, step0, seeds, rf, batch=8, out=None, to_host=True):
         """n_steps Metropolis steps for every chain with on-device proposals.
         Returns (loss, accept, blocks): (n_chains, n_steps), (n_chains, n_steps), (n_chains, n_steps, 4)."""

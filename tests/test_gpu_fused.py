@@ -16,6 +16,7 @@ def _run_both(eng, beds0, n, step0, seeds, rfp, batch):
         eng.set_fused(fused)
         eng.set_state(beds0)
         loss, acc, blk = eng.run_philox(n, step0, seeds, rfp, batch=batch)
+        assert eng.last_run_fused() == fused      # the path under test really ran
         res.append((loss, acc, blk, eng.beds.cpu().numpy().copy(), eng.resampled.cpu().numpy().copy(),
                     eng.energy.cpu().numpy().copy(), eng.loss_sum.cpu().numpy().copy()))
     return res
@@ -54,6 +55,7 @@ def test_fused_256_headline_blocks_equal_propose_then_replay():
     eng.set_fused(True)
     eng.set_state(beds0)
     lossA, accA, blkA = eng.run_philox(n, 0, seeds, rfp, batch=n)
+    assert eng.last_run_fused()
     bedA = eng.beds.cpu().numpy().copy()
     resA = eng.resampled.cpu().numpy().copy()
     eng.set_state(beds0)
@@ -91,6 +93,7 @@ def test_fused_segments_reproduce_unsplit_run():
     beds0 = np.stack([orc.chain_initial_bed(prob, c) for c in range(3)])
     eng.set_state(beds0)
     loss, acc, blk = eng.run_philox(50, 1000, seeds, rfp)
+    assert eng.last_run_fused()
     bed = eng.beds.cpu().numpy().copy()
     eng.set_state(beds0)
     l1, a1, b1 = eng.run_philox(23, 1000, seeds, rfp)
