@@ -159,10 +159,12 @@ int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int32_t batch, 
                    const gsm_rf_params* rf, void* beds, void* energy, uint32_t* resampled, double* loss_sum,
                    double* loss, uint8_t* accept, int32_t* blocks, void* stream);
 
-/* Select the launch structure of gsm_run_philox for the spectral generator on this handle: 1 = fused chain kernel
- * (default), 0 = two-kernel pipeline.  Identical results; kept for A/B measurements and tests. */
+/* Select the launch structure of gsm_run_philox for the spectral generator on this handle: 1 = fused chain kernel, one
+ * 1024-thread workgroup per CU (default); 2 = fused chain kernel, two 512-thread workgroups per CU; 0 = two-kernel
+ * pipeline.  Identical results; kept for A/B measurements and tests.  Environment default: GSM_FUSED. */
 int gsm_set_fused(gsm_handle h, int32_t on);
-/* 1 if the last gsm_run_philox call on this handle ran the fused chain kernel, 0 if the two-kernel pipeline. */
+/* Which form the last gsm_run_philox call on this handle ran: 1 / 2 = fused chain kernel (1024 / 512 threads), 0 = the
+ * two-kernel pipeline. */
 int gsm_last_run_fused(gsm_handle h);
 
 /* Average duration in milliseconds of the step kernel / the proposal kernel over the launches made

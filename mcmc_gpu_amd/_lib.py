@@ -16,13 +16,14 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libgsm_hip.so"
 HEADER = PKG_DIR.parent / "include" / "gsm.h"
-SOURCES = ["gsm_api.hip", "step_kernel.hip", "step_flux_kernel.hip", "chain_fused_kernel.hip", "proposal_kernel.hip", "cholesky_kernel.hip"]
+SOURCES = ["gsm_api.hip", "step_kernel.hip", "step_flux_kernel.hip", "chain_fused_kernel.hip", "chain_fused512_kernel.hip", "proposal_kernel.hip", "cholesky_kernel.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-Wno-unused-value", "-Wno-unused-result"]
 # per-file extras.  step_flux_kernel: without machine LICM the fp64 polynomial constants of exp() are materialised at
 # their use instead of being hoisted out of the step loop into ~30 VGPRs that are then spilled.
 EXTRA_FLAGS = {"step_flux_kernel.hip": ["-mllvm", "-disable-machine-licm"],
-               "chain_fused_kernel.hip": ["-mllvm", "-disable-machine-licm"]}
+               "chain_fused_kernel.hip": ["-mllvm", "-disable-machine-licm"],
+               "chain_fused512_kernel.hip": ["-mllvm", "-disable-machine-licm"]}
 OBJ_DIR = PKG_DIR / "_build"
 
 

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
           ve[k] = StateIO<TS>::load(r_en, inwin ? g * (uint32_t)sizeof(TS) : kOOB);
         }
       },
-      fld);
+      fld, [bw](int y, int x) { return y * bw + x; });
 #ifdef GSM_STAMPS
     if (tid == 0) {
       const unsigned long long* ps = (const unsigned long long*)(red2 + 32);

@@ -461,7 +461,7 @@ extern "C" int gsm_last_run_fused(gsm_handle h) { return h ? h->last_fused : GSM
 
 extern "C" int gsm_set_fused(gsm_handle h, int32_t on) {
   if (!h) return GSM_E_ARG;
-  h->use_fused = on ? 1 : 0;
+  h->use_fused = (on == 2) ? 2 : (on ? 1 : 0);
   return GSM_OK;
 }
 
@@ -497,7 +497,7 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
   // Spectral generator: one fused launch (chain_fused_kernel.hip) -- proposals are generated and consumed on the CU,
   // no field scratch, no second stream.  GSM_FUSED=0 keeps the two-kernel pipeline (also used by the Cholesky generator
   // and by block tables beyond the fused kernel's LDS budget).
-  if (h->use_fused < 0) { const char* v = getenv("GSM_FUSED"); h->use_fused = (v && atoi(v) == 0) ? 0 : 1; }
+  if (h->use_fused < 0) { const char* v = getenv("GSM_FUSED"); h->use_fused = v ? atoi(v) : 1; }
   h->last_fused = 0;
   if (h->use_fused && rf->generator == GSM_GEN_SPECTRAL) {
     FusedArgs fa{};
@@ -513,8 +513,9 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
     fa.P.scalars = h->d_scalars[0];
     // the scalars kernel also writes (size_idx, centre, u) records: give it the scalar-sized scratch of slot 1
     h->last_fused = 0;
-    if (fused_supported(fa)) {
-      h->last_fused = 1;
+    const bool want512 = h->use_fused == 2 && fused512_supported(fa);
+    if (want512 || fused_supported(fa)) {
+      h->last_fused = want512 ? 2 : 1;
       const size_t recs1 = (size_t)h->n_chains * n_steps;
       auto& sc = h->scr[1];
       if (sc.recs < recs1 || sc.fields) {
@@ -529,7 +530,8 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
       if (h->timing) { HIPCHK(h, hipEventCreate(&t0)); HIPCHK(h, hipEventCreate(&t1)); }
       HIPCHK(h, launch_propose_scalars(fa.P, st));
       if (h->timing) HIPCHK(h, hipEventRecord(t0, st));
-      HIPCHK(h, launch_chain_fused(fa, st));
+      if (want512) HIPCHK(h, launch_chain_fused512(fa, st));
+      else HIPCHK(h, launch_chain_fused(fa, st));
       if (h->timing) HIPCHK(h, hipEventRecord(t1, st));
       rc = check_device_flag(h, st, "gsm_run_philox");
       if (h->timing) {

@@ -147,6 +147,8 @@ hipError_t launch_propose(const ProposeArgs& a, hipStream_t st);
 hipError_t launch_propose_scalars(const ProposeArgs& a, hipStream_t st);
 hipError_t launch_chain_fused(const FusedArgs& a, hipStream_t st);
 bool fused_supported(const FusedArgs& a);
+hipError_t launch_chain_fused512(const FusedArgs& a, hipStream_t st);
+bool fused512_supported(const FusedArgs& a);
 int propose_max_tiles_per_wave();
 int propose_max_tiles1_per_wave();
 int propose_waves();

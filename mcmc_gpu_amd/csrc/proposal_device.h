@@ -102,7 +102,9 @@ __device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const Pro
 // and the mirrored output is  U[y] - i V[y]  at n - y.  Only k, y in [0, h] enter the products: 4x fewer flops than the
 // dense complex DFT.  The real (c2r) stage folds the same way in x: field[y][x] = E + O, field[y][bw - x] = E - O.
 // plds: LDS work area of a.lds_main doubles (the four coefficient planes, overlaid by T^T); red: 32 doubles of LDS.
-// out: receives the finished (scaled, masked) field, cell o = y * bw + x (global memory or LDS).
+// out: receives the finished (scaled, masked) field (global memory or LDS): cell (y, x) goes to out[omap(y, x)], or
+// nowhere if omap returns a negative index (the 512-thread fused kernel stores only the part of the block inside the
+// grid, at its position in the window tile).
 // Contains workgroup barriers: every thread of the workgroup must call it with the same (uniform) arguments.  On return
 // other waves may still be reading `red`; the planes are free once every wave has returned.
 //
@@ -116,10 +118,10 @@ __device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const Pro
 // must issue exactly HOOK_VMEM vector-memory instructions --
 // the fused kernel issues the loads of the chain state there, so that they fly during the two MFMA stages without
 // occupying registers during the register-hungry coefficient phase.
-template <int NT, bool TABLDS, int HOOK_VMEM, class Hook>
+template <int NT, bool TABLDS, int HOOK_VMEM, class Hook, class OMap>
 __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& a, const PropScalars& sc, const uint64_t seed,
                                               const int64_t step, double* plds, double* red, double* tabA, double* tabG, Hook after_coeff,
-                                              double* __restrict__ out) {
+                                              double* __restrict__ out, OMap omap) {
   constexpr int NW = NT / 64, MAXT = 16 / NW;
   const int SX = a.lds_sx, ST = a.lds_st;
   double* Pr = plds;                       // 4 planes [KRmax][SX]: P re, P im, M re, M im
@@ -392,9 +394,11 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           if (half == 1 && !(x > 0 && x < hw)) continue;
-          const int o = y * bw + (half ? bw - x : x);
+          const int xx = half ? bw - x : x;
+          const int o = y * bw + xx;
+          const int oi = omap(y, xx);
           const double v = ((half ? fo[j][q] : fe[j][q]) - mean) * gain;
-          out[o] = with_nugget ? v : v * (TABLDS ? mreg[j][2 * q + half] : mask[o]);
+          if (oi >= 0) out[oi] = with_nugget ? v : v * (TABLDS ? mreg[j][2 * q + half] : mask[o]);
         }
       }
     }
@@ -406,8 +410,10 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
       double n1, n2;
       normals2(seed, step, kStreamNugget, (uint32_t)pr, n1, n2);
       const int o = 2 * pr;
-      out[o] = (out[o] + n1 * sq_nug) * mask[o];
-      out[o + 1] = (out[o + 1] + n2 * sq_nug) * mask[o + 1];
+      const int y = o / bw, x = o - y * bw;       // bw is even: the pair (o, o + 1) lies in one row
+      const int o0 = omap(y, x), o1 = omap(y, x + 1);
+      if (o0 >= 0) out[o0] = (out[o0] + n1 * sq_nug) * mask[o];
+      if (o1 >= 0) out[o1] = (out[o1] + n2 * sq_nug) * mask[o + 1];
     }
   }
 }

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(NT, NT / 256) void propose_kernel(const ProposeArgs
   const PropScalars sc = a.scalars[rec];
   if (a.dbg & 64) { if (threadIdx.x == 0) a.fields[rec * a.field_stride] = (double)sc.bh; return; }
   double* __restrict__ out = a.fields + rec * a.field_stride;
-  propose_field<NT, false, 0>((int)threadIdx.x, a, sc, a.seeds[chain], a.step0 + s, plds, red, nullptr, nullptr, [] {}, out);
+  propose_field<NT, false, 0>((int)threadIdx.x, a, sc, a.seeds[chain], a.step0 + s, plds, red, nullptr, nullptr, [] {}, out,
+                              [bw = sc.bw](int y, int x) { return y * bw + x; });
 }
 
 hipError_t launch_propose(const ProposeArgs& a_in, hipStream_t st) {

@@ -262,10 +262,10 @@ class GsmEngine:
 
     def set_fused(self, on: bool):
         """Philox mode, spectral generator: fused chain kernel (default) or the two-kernel pipeline (same results)."""
-        self._check(self.lib.gsm_set_fused(self.h, 1 if on else 0))
+        self._check(self.lib.gsm_set_fused(self.h, int(on)))   # 0 two kernels, 1 fused (1024 threads), 2 fused (512 threads x 2 per CU)
 
-    def last_run_fused(self) -> bool:
-        return bool(self.lib.gsm_last_run_fused(self.h))
+    def last_run_fused(self) -> int:
+        return int(self.lib.gsm_last_run_fused(self.h))
 
     def run_philox(self, n_steps, step0, seeds, rf, batch=8, out=None, to_host=True):
         """n_steps Metropolis steps for every chain with on-device proposals.

@@ -103,3 +103,27 @@ def test_fused_segments_reproduce_unsplit_run():
     assert np.array_equal(np.concatenate([b1, b2], axis=1), blk)
     assert np.array_equal(bed, eng.beds.cpu().numpy())
     eng.close()
+
+
+def test_fused_512_thread_form_equals_1024_thread_form():
+    """gsm_set_fused(h, 2): two 512-thread workgroups per CU (bed tile updated in place, stencil operands from L2).
+    Different data placement, same arithmetic and summation order: bit-identical to the 1024-thread kernel."""
+    rfp = orc.standard_rf_params()
+    for H, n_chains, n in ((64, 4, 45), (256, 2, 24)):
+        eng, prob, cfg, pairs, masks, _ = make_engine(H, n_chains)
+        rfp.resolution = prob["resolution"]
+        if H == 256:
+            eng.set_centres(np.ones_like(cfg.region_mask))     # clipped windows too
+        seeds = [61 + c for c in range(n_chains)]
+        beds0 = np.stack([orc.chain_initial_bed(prob, c) for c in range(n_chains)])
+        res = []
+        for mode in (1, 2):
+            eng.set_fused(mode)
+            eng.set_state(beds0)
+            loss, acc, blk = eng.run_philox(n, 9, seeds, rfp)
+            assert eng.last_run_fused() == mode
+            res.append((loss, acc, blk, eng.beds.cpu().numpy().copy(), eng.resampled.cpu().numpy().copy(),
+                        eng.energy.cpu().numpy().copy(), eng.loss_sum.cpu().numpy().copy()))
+        for x, y in zip(*res):
+            assert np.array_equal(x, y)
+        eng.close()
