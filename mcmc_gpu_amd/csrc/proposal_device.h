@@ -48,6 +48,29 @@ __device__ __forceinline__ double log_pos(double x) {
   return dk * 6.93147180369123816490e-01 - ((hfsq - __fma_rn(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
 }
 
+// (sin, cos)(2 pi u) for u in [0, 1): quadrant reduction on a = 4u (exact: n = rint(a), f = a - n in [-1/2, 1/2]), then the
+// fdlibm __kernel_sin / __kernel_cos polynomials on x = f pi/2, |x| <= pi/4.  Absolute error < 1.5e-16 (host check against
+// long double over 2e7 arguments); no large-argument reduction, no special cases: about 60 % of the library sincospi.
+__device__ __forceinline__ void sincos_2pi(double u, double& s, double& c) {
+  const double a = 4.0 * u;
+  const double n = __builtin_rint(a);
+  const double x = (a - n) * 1.57079632679489661923;
+  const double z = x * x;
+  const double ps = __fma_rn(z, __fma_rn(z, __fma_rn(z, __fma_rn(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                                      2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                             8.33333333332248946124e-03);
+  const double sn = __fma_rn(x * z, __fma_rn(z, ps, -1.66666666666666324348e-01), x);
+  const double pc = __fma_rn(z, __fma_rn(z, __fma_rn(z, __fma_rn(z, __fma_rn(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                                  -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                          -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double cs = w + (((1.0 - w) - hz) + z * (z * pc));
+  const int q = (int)n;                    // 0..4
+  const double ss = (q & 1) ? cs : sn, cc = (q & 1) ? sn : cs;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
+
 __device__ __forceinline__ void normals2(uint64_t seed, int64_t step, uint32_t stream, uint32_t idx, double& g1,
                                          double& g2) {
   const u32x4 r = philox_draw(seed, step, stream, idx);
@@ -55,7 +78,7 @@ __device__ __forceinline__ void normals2(uint64_t seed, int64_t step, uint32_t s
   const double u2 = u01_from(r.z, r.w);
   const double rad = sqrt(-2.0 * log_pos(u1));
   double s, c;
-  sincospi(2.0 * u2, &s, &c);
+  sincos_2pi(u2, s, c);
   g1 = rad * c;
   g2 = rad * s;
 }
