@@ -165,56 +165,88 @@ __global__ __launch_bounds__(kT5, 4) void chain_fused512_kernel(const FusedArgs 
     }
     __syncthreads();
 
-    // ---- D: residual stencil: bed neighbours from the tile, their (surf, vel) from L2 ------------------------
+    // ---- D: residual stencil: bed neighbours from the tile, their (surf, vel) from L2; an x pass (d/dx of the x flux
+    // kept in e_new[]) and a y pass, so that only two resp. three 16-byte operands per cell are in flight ------------
     double e_new[KT];
     double acc_new0 = 0.0, acc_new1 = 0.0;
+    constexpr int KX = (KD == 1) ? 2 : 4, KY = (KD == 1) ? 1 : 2;
 #pragma unroll
-    for (int kb = 0; kb < KT; kb += KD) {
-      double2 xr[KD], xl[KD], yd[KD], yu[KD], C2[KD];
+    for (int kb = 0; kb < KT; kb += KX) {
+      double2 xr[KX], xl[KX];
       asm volatile("" : "+v"(ptid) :: "memory");
 #pragma unroll
-      for (int j = 0; j < KD; ++j) {
+      for (int j = 0; j < KX; ++j) {
         const int k = kb + j;
-        int i, lr, lc; uint32_t g; bool valid, inwin;
-        cell(k, i, lr, lc, g, valid, inwin);
-        const int r = hr0 + lr, c = hc0 + lc;
-        const uint32_t gl = (c == 0) ? g : g - 1, gr = (c == W - 1) ? g : g + 1;
-        const uint32_t gu = (r == 0) ? g : g - (uint32_t)W, gd = (r == H - 1) ? g : g + (uint32_t)W;
-        xr[j] = ld_f64x2(r_vx, inwin ? gr * 16u : kOOB);
-        xl[j] = ld_f64x2(r_vx, inwin ? gl * 16u : kOOB);
-        yd[j] = ld_f64x2(r_vy, inwin ? gd * 16u : kOOB);
-        yu[j] = ld_f64x2(r_vy, inwin ? gu * 16u : kOOB);
-        C2[j] = ld_f64x2(r_sC, inwin ? g * 16u : kOOB);
+        if (k < KT) {
+          int i, lr, lc; uint32_t g; bool valid, inwin;
+          cell(k, i, lr, lc, g, valid, inwin);
+          const int c = hc0 + lc;
+          const uint32_t gl = (c == 0) ? g : g - 1, gr = (c == W - 1) ? g : g + 1;
+          xr[j] = ld_f64x2(r_vx, inwin ? gr * 16u : kOOB);
+          xl[j] = ld_f64x2(r_vx, inwin ? gl * 16u : kOOB);
+        }
       }
 #pragma unroll
-      for (int j = 0; j < KD; ++j) {
+      for (int j = 0; j < KX; ++j) {
         const int k = kb + j;
-        int i, lr, lc; uint32_t g; bool valid, inwin;
-        cell(k, i, lr, lc, g, valid, inwin);
-        const int r = hr0 + lr, c = hc0 + lc;
-        const int il = (c == 0) ? i : i - 1, ir = (c == W - 1) ? i : i + 1;
-        const int iu = (r == 0) ? i : i - tw, id = (r == H - 1) ? i : i + tw;
-        double e = 0.0;
-        if (inwin) {
-          const double qxr = xr[j].y * (xr[j].x - tile[ir]);
-          const double qxl = xl[j].y * (xl[j].x - tile[il]);
-          const double qyd = yd[j].y * (yd[j].x - tile[id]);
-          const double qyu = yu[j].y * (yu[j].x - tile[iu]);
-          const double ddx = qxr - qxl, ddy = qyd - qyu;
-          double dx, dy;
-          if (FAST_DIV) {
-            dx = (ir - il == 2) ? exact_div(ddx, S.two_res, S.rcp_two_res) : exact_div(ddx, S.res, S.rcp_res);
-            dy = (id - iu == 2 * tw) ? exact_div(ddy, S.two_res, S.rcp_two_res) : exact_div(ddy, S.res, S.rcp_res);
-          } else {
-            dx = ddx / ((ir - il == 2) ? S.two_res : S.res);
-            dy = ddy / ((id - iu == 2 * tw) ? S.two_res : S.res);
+        if (k < KT) {
+          int i, lr, lc; uint32_t g; bool valid, inwin;
+          cell(k, i, lr, lc, g, valid, inwin);
+          const int c = hc0 + lc;
+          const int il = (c == 0) ? i : i - 1, ir = (c == W - 1) ? i : i + 1;
+          double dx = 0.0;
+          if (inwin) {
+            const double qxr = xr[j].y * (xr[j].x - tile[ir]);
+            const double qxl = xl[j].y * (xl[j].x - tile[il]);
+            const double ddx = qxr - qxl;
+            if (FAST_DIV) dx = (ir - il == 2) ? exact_div(ddx, S.two_res, S.rcp_two_res) : exact_div(ddx, S.res, S.rcp_res);
+            else dx = ddx / ((ir - il == 2) ? S.two_res : S.res);
           }
-          const double v = ((dx + dy) + C2[j].x) - C2[j].y;
-          if (!isnan(v)) e = v * v;
-          if (F32) e = (double)(float)e;
+          e_new[k] = dx;
         }
-        e_new[k] = e;
-        if (k & 1) acc_new1 += e; else acc_new0 += e;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int kb = 0; kb < KT; kb += KY) {
+      double2 yd[KY], yu[KY], C2[KY];
+      asm volatile("" : "+v"(ptid) :: "memory");
+#pragma unroll
+      for (int j = 0; j < KY; ++j) {
+        const int k = kb + j;
+        if (k < KT) {
+          int i, lr, lc; uint32_t g; bool valid, inwin;
+          cell(k, i, lr, lc, g, valid, inwin);
+          const int r = hr0 + lr;
+          const uint32_t gu = (r == 0) ? g : g - (uint32_t)W, gd = (r == H - 1) ? g : g + (uint32_t)W;
+          yd[j] = ld_f64x2(r_vy, inwin ? gd * 16u : kOOB);
+          yu[j] = ld_f64x2(r_vy, inwin ? gu * 16u : kOOB);
+          C2[j] = ld_f64x2(r_sC, inwin ? g * 16u : kOOB);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < KY; ++j) {
+        const int k = kb + j;
+        if (k < KT) {
+          int i, lr, lc; uint32_t g; bool valid, inwin;
+          cell(k, i, lr, lc, g, valid, inwin);
+          const int r = hr0 + lr;
+          const int iu = (r == 0) ? i : i - tw, id = (r == H - 1) ? i : i + tw;
+          double e = 0.0;
+          if (inwin) {
+            const double qyd = yd[j].y * (yd[j].x - tile[id]);
+            const double qyu = yu[j].y * (yu[j].x - tile[iu]);
+            const double ddy = qyd - qyu;
+            double dy;
+            if (FAST_DIV) dy = (id - iu == 2 * tw) ? exact_div(ddy, S.two_res, S.rcp_two_res) : exact_div(ddy, S.res, S.rcp_res);
+            else dy = ddy / ((id - iu == 2 * tw) ? S.two_res : S.res);
+            const double v = ((e_new[k] + dy) + C2[j].x) - C2[j].y;
+            if (!isnan(v)) e = v * v;
+            if (F32) e = (double)(float)e;
+          }
+          e_new[k] = e;
+          if (k & 1) acc_new1 += e; else acc_new0 += e;
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
