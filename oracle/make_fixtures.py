@@ -115,6 +115,77 @@ def run_pair(M, H, n_iter, chain_index, rfp, block_type, update_in_region, tag):
     return prob, cfg, pairs, masks, out
 
 
+def sgs_problem(H=32, res=500.0):
+    """Synthetic inputs of the small-scale-chain fixture: the standard problem on a small grid, conditioning data on
+    every 4th row and every 8th column (so that octant searches find neighbours everywhere), a smooth trend."""
+    prob = orc.synthetic_problem(H, res=res)
+    data_mask = np.zeros((H, H), dtype=bool)
+    data_mask[::4, :] = True
+    data_mask[:, ::8] = True
+    prob["data_mask"] = data_mask
+    prob["cond_bed"] = np.where(data_mask, prob["bed"], np.nan)
+    region = np.zeros((H, H), dtype=int)
+    region[H // 8: 7 * H // 8, H // 8: 7 * H // 8] = 1
+    prob["region_mask"] = region
+    Lx = H * res
+    prob["trend"] = prob["surf"] - 1000.0 - 150.0 * np.cos(4 * np.pi * prob["xx"] / Lx)
+    return prob
+
+
+def make_f10_sgs(M):
+    """F10: chain_sgs.run of the reference vs oracle/sgs_oracle.py, two variants:
+    (a) exponential variogram, no transform, no trend; (b) Matern variogram, detrended, normal-score transform."""
+    import sgs_oracle as so
+    from sklearn.preprocessing import QuantileTransformer
+    H, n_iter = 32, 14
+    prob = sgs_problem(H)
+    out = {}
+    for tag, vtype, smooth, use_trend, use_nst, seed, sigma in (("a", "Exponential", None, False, False, 11, 60.0),
+                                                                ("b", "Matern", 1.5, True, True, 12, 5.0)):
+        trend = prob["trend"] if use_trend else None
+        base = prob["bed"] - trend if use_trend else prob["bed"]
+        nst = None
+        if use_nst:
+            data = (prob["cond_bed"] - trend if use_trend else prob["cond_bed"])[prob["data_mask"]].reshape(-1, 1)
+            nst = QuantileTransformer(n_quantiles=200, output_distribution="normal", random_state=152).fit(data)
+        sill = float(np.var((nst.transform(base.reshape(-1, 1)) if use_nst else base.reshape(-1, 1))))
+        rng_range, nug = 6000.0, 0.0
+        with quiet():
+            ch = M.chain_sgs(prob["xx"], prob["yy"], prob["bed"], prob["surf"], prob["velx"], prob["vely"], prob["dhdt"],
+                             prob["smb"], prob["cond_bed"], prob["data_mask"], np.ones((H, H), dtype=int), prob["resolution"])
+            ch.set_update_region(True, prob["region_mask"])
+            ch.set_loss_type(sigma_mc=sigma, massConvInRegion=True)
+            ch.set_normal_transformation(nst, do_transform=use_nst)
+            ch.set_trend(trend, detrend_map=use_trend)
+            ch.set_variogram(vtype, rng_range, sill, nug, isotropic=True, vario_smoothness=smooth)
+            ch.set_sgs_param(16, 4000.0)
+            ch.set_block_sizes(3, 8, 3, 8)
+            ch.set_random_generator(rng_seed=seed)
+            with warnings_off():
+                ref = ch.run(n_iter, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=False)
+        ref_state = ch.rng.bit_generator.state
+        cfg = so.SgsConfig(prob["xx"], prob["yy"], prob["surf"], prob["velx"], prob["vely"], prob["dhdt"], prob["smb"],
+                           prob["cond_bed"], prob["data_mask"], np.ones((H, H), dtype=int), prob["region_mask"],
+                           prob["resolution"], sigma, [0, nug, rng_range, rng_range, sill, vtype, smooth], [16, 4000.0, False, 0],
+                           3, 8, 3, 8, trend=trend, nst_trans=nst)
+        rng = np.random.default_rng(seed=seed)
+        trace = []
+        with warnings_off():
+            mine = so.run_chain_sgs(cfg, prob["bed"], n_iter, rng, trace=trace)
+        for k, name in enumerate(("bed", "loss_mc", "loss_data", "loss", "steps", "resampled", "blocks")):
+            same(ref[k], mine[k], f"F10{tag} {name}")
+        assert rng.bit_generator.state == ref_state, f"F10{tag}: final RNG state differs"
+        tr = np.array(trace)
+        out.update({f"{tag}_bed": mine[0], f"{tag}_loss": mine[3], f"{tag}_steps": mine[4], f"{tag}_resampled": mine[5],
+                    f"{tag}_blocks": mine[6], f"{tag}_sill": sill, f"{tag}_seed": seed, f"{tag}_sigma_mc": sigma,
+                    f"{tag}_trace_head": tr[:40], f"{tag}_trace_sha": sha(tr), f"{tag}_n_sim": len(trace),
+                    f"{tag}_rng_state": json.dumps(ref_state)})
+        print(f"F10{tag}: oracle == reference over {n_iter} iterations ({len(trace)} simulated cells, "
+              f"accept {mine[4].mean():.2f})")
+    np.savez_compressed(GOLD / "f10_sgs_chain32.npz", H=H, n_iter=n_iter, range=6000.0, radius=4000.0, num_points=16,
+                        **out)
+
+
 def main():
     M, T, G, C = ref_loader.load_reference()
     GOLD.mkdir(parents=True, exist_ok=True)
@@ -238,6 +309,8 @@ def main():
         hv = T.get_highvel_boundary(velx9, vely9, 60.0, grounded9, ocean9, 2500.0, xx9, yy9, smooth_mode=5)
     np.savez_compressed(GOLD / "f9_highvel_boundary.npz", velx=velx9, vely=vely9, grounded=grounded9, ocean=ocean9,
                         xx=xx9, yy=yy9, threshold=60.0, distance_max=2500.0, smooth_mode=5, mask_final=hv)
+
+    make_f10_sgs(M)
 
     print("fixtures written to", GOLD)
     for p in sorted(GOLD.iterdir()):

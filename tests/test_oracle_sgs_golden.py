@@ -1,0 +1,84 @@
+"""not gpu: the small-scale-chain restatement (oracle/sgs_oracle.py) against golden F10, generated from the imported
+reference with bit-identity asserted (oracle/make_fixtures.py: make_f10_sgs).  Groundwork for SURVEY.md section 8f
+rank 3 -- there is no HIP path for chain_sgs yet; this pins the CPU checker the HIP path will be tested against."""
+import hashlib
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "oracle"))
+import mcmc_oracle as orc  # noqa: E402
+import sgs_oracle as so  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden" / "f10_sgs_chain32.npz"
+
+
+def _problem(H):
+    """Same synthetic inputs as make_fixtures.sgs_problem (kept in step by the fixture values themselves)."""
+    prob = orc.synthetic_problem(H, res=500.0)
+    data_mask = np.zeros((H, H), dtype=bool)
+    data_mask[::4, :] = True
+    data_mask[:, ::8] = True
+    prob["data_mask"] = data_mask
+    prob["cond_bed"] = np.where(data_mask, prob["bed"], np.nan)
+    region = np.zeros((H, H), dtype=int)
+    region[H // 8: 7 * H // 8, H // 8: 7 * H // 8] = 1
+    prob["region_mask"] = region
+    prob["trend"] = prob["surf"] - 1000.0 - 150.0 * np.cos(4 * np.pi * prob["xx"] / (H * 500.0))
+    return prob
+
+
+@pytest.mark.parametrize("tag,vtype,smooth,use_trend,use_nst", [("a", "Exponential", None, False, False),
+                                                                ("b", "Matern", 1.5, True, True)])
+def test_sgs_oracle_reproduces_reference_fixture(tag, vtype, smooth, use_trend, use_nst):
+    g = np.load(GOLD, allow_pickle=False)
+    H, n_iter = int(g["H"]), int(g["n_iter"])
+    prob = _problem(H)
+    trend = prob["trend"] if use_trend else None
+    nst = None
+    if use_nst:
+        from sklearn.preprocessing import QuantileTransformer
+        data = (prob["cond_bed"] - trend)[prob["data_mask"]].reshape(-1, 1)
+        nst = QuantileTransformer(n_quantiles=200, output_distribution="normal", random_state=152).fit(data)
+    sill, seed, sigma = float(g[f"{tag}_sill"]), int(g[f"{tag}_seed"]), float(g[f"{tag}_sigma_mc"])
+    rr, rad, npts = float(g["range"]), float(g["radius"]), int(g["num_points"])
+    cfg = so.SgsConfig(prob["xx"], prob["yy"], prob["surf"], prob["velx"], prob["vely"], prob["dhdt"], prob["smb"],
+                       prob["cond_bed"], prob["data_mask"], np.ones((H, H), dtype=int), prob["region_mask"],
+                       prob["resolution"], sigma, [0, 0.0, rr, rr, sill, vtype, smooth], [npts, rad, False, 0],
+                       3, 8, 3, 8, trend=trend, nst_trans=nst)
+    rng = np.random.default_rng(seed=seed)
+    trace = []
+    out = so.run_chain_sgs(cfg, prob["bed"], n_iter, rng, trace=trace)
+    assert np.array_equal(out[0], g[f"{tag}_bed"])
+    assert np.array_equal(out[3], g[f"{tag}_loss"])
+    assert np.array_equal(out[4], g[f"{tag}_steps"])
+    assert np.array_equal(out[5], g[f"{tag}_resampled"])
+    assert np.array_equal(out[6], g[f"{tag}_blocks"])
+    assert rng.bit_generator.state == json.loads(str(g[f"{tag}_rng_state"]))
+    tr = np.array(trace)
+    assert len(trace) == int(g[f"{tag}_n_sim"])
+    assert np.array_equal(tr[:40], g[f"{tag}_trace_head"])
+    assert hashlib.sha256(np.ascontiguousarray(tr).tobytes()).hexdigest() == str(g[f"{tag}_trace_sha"])
+
+
+def test_octant_search_properties():
+    """neighbors(): at most num_points // 8 points per 45-degree sector, all within the radius, nearest first."""
+    H = 24
+    prob = _problem(H)
+    grid = prob["cond_bed"].copy()
+    cond = ~np.isnan(grid)
+    ii, jj = np.meshgrid(np.arange(H), np.arange(H), indexing="ij")
+    stencil, _, _ = so.make_circle_stencil(prob["xx"][0, :], 3000.0)
+    pts = so.neighbors(10, 13, ii, jj, prob["xx"], prob["yy"], grid, cond, 3000.0, 16, stencil=stencil)
+    assert 0 < pts.shape[0] <= 16
+    d = np.hypot(pts[:, 0] - prob["xx"][10, 13], pts[:, 1] - prob["yy"][10, 13])
+    assert (d < 3000.0).all()
+    ang = np.arctan2(prob["yy"][10, 13] - pts[:, 1], prob["xx"][10, 13] - pts[:, 0])
+    sector = np.ceil(ang / (np.pi / 4)).astype(int)
+    for s_ in np.unique(sector):
+        ds = d[sector == s_]
+        assert ds.size <= 2 and (np.diff(ds) >= 0).all()
