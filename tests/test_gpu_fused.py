@@ -127,3 +127,34 @@ def test_fused_512_thread_form_equals_1024_thread_form():
         for x, y in zip(*res):
             assert np.array_equal(x, y)
         eng.close()
+
+
+def test_fused_nan_fields_and_thickness_guard_equal_two_kernel_pipeline():
+    """NaN holes in the bed, a NaN velocity patch, a NaN dhdt cell (nansum semantics, MCMC.py:1041, :1328) and a surface
+    lowered so far in one corner that proposals there trip the thickness guard (loss = inf, MCMC.py:1321-1329): the fused
+    kernel's NaN-coded operands must give what the mask-byte kernels give (which replay tests pin to the oracle)."""
+    from mcmc_gpu_amd.engine import GsmEngine
+    rfp = orc.standard_rf_params()
+    prob, cfg, pairs, masks, _ = orc.standard_setup(64)
+    cfg.velx = cfg.velx.copy(); cfg.velx[30:33, 40:44] = np.nan
+    cfg.dhdt = cfg.dhdt.copy(); cfg.dhdt[12, 12] = np.nan
+    cfg.surf = cfg.surf.copy(); cfg.surf[8:30, 8:30] = prob["bed"][8:30, 8:30] + 6.0      # 6 m of ice over beds that start 0-15 m off: guard country
+    eng = GsmEngine(64, 64, 6)
+    eng.set_static(cfg.surf, cfg.velx, cfg.vely, cfg.dhdt, cfg.smb, cfg.crf_data_weight, cfg.region_mask,
+                   cfg.mc_region_mask, cfg.resolution, cfg.sigma_mc)
+    eng.set_blocks(pairs, masks)
+    eng.set_centres(cfg.region_mask)
+    rfp.resolution = prob["resolution"]
+    beds0 = np.stack([orc.chain_initial_bed(prob, c) for c in range(6)])
+    beds0[:, 50, 20:23] = np.nan
+    seeds = [71 + c for c in range(6)]
+    a, b = _run_both(eng, beds0, 80, 0, seeds, rfp, batch=16)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    loss, acc, blk = a[0], a[1], a[2]
+    assert np.isfinite(loss).all()
+    # proposals centred in the thin-ice corner are (almost) always rejected by the guard, the others are not
+    in_corner = (blk[..., 0] >= 12) & (blk[..., 0] < 26) & (blk[..., 1] >= 12) & (blk[..., 1] < 26)
+    assert in_corner.sum() > 5
+    assert acc[in_corner].mean() < 0.5 * acc[~in_corner].mean()
+    eng.close()
