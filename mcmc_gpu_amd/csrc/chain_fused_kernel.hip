@@ -385,6 +385,7 @@ bool fused_supported(const FusedArgs& a) {
 hipError_t launch_chain_fused(const FusedArgs& a_in, hipStream_t st) {
   if (!fused_supported(a_in)) return hipErrorInvalidValue;
   FusedArgs a = a_in;
+  { static int dbg = -1; if (dbg < 0) { const char* v = getenv("GSM_PROPOSE_DBG"); dbg = v ? atoi(v) : 0; } a.P.dbg = dbg; }   // diagnostics only
   a.work_len = fused_work_len(a);
   a.fld_len = fused_fld_len(a);
   if (a.T.f32_state) {
