@@ -73,7 +73,12 @@ __device__ __forceinline__ void sincos_2pi(double u, double& s, double& c) {
 
 __device__ __forceinline__ void normals2(uint64_t seed, int64_t step, uint32_t stream, uint32_t idx, double& g1,
                                          double& g2) {
-  const u32x4 r = philox_draw(seed, step, stream, idx);
+  // The 20 round keys are uniform functions of the seed: left alone, the compiler computes them once per kernel and
+  // holds 20 SGPRs for ever (spilled to VGPR lanes and read back with v_readlane, a vector instruction, at every use).
+  // Laundering the seed here makes them 20 scalar adds per call instead.
+  uint32_t k0 = (uint32_t)(seed & 0xFFFFFFFFu), k1 = (uint32_t)(seed >> 32);
+  asm volatile("" : "+s"(k0), "+s"(k1));
+  const u32x4 r = philox_draw(((uint64_t)k1 << 32) | k0, step, stream, idx);
   const double u1 = u01_open0_from(r.x, r.y);
   const double u2 = u01_from(r.z, r.w);
   const double rad = sqrt(-2.0 * log_pos(u1));
