@@ -100,7 +100,7 @@ __device__ __forceinline__ double wavenumber(int k, int n, double res) {
 template <int NT>
 __device__ __forceinline__ double tiles_sum(const double (&part)[16 / (NT / 64)], int n_tiles, double* red, int tid) {
   constexpr int NW = NT / 64, MAXT = 16 / NW;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
     const double w = dev::wave64_sum(part[j]);
@@ -157,7 +157,10 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
   double* Mr = Pi + a.lds_x_half;
   double* Mi = Mr + a.lds_x_half;
   double* TT = plds;                       // [2 Kc][ST]  -- overlays the planes once stage 1 has consumed them
-  const int lane = tid & 63, wave = tid >> 6;   // tid: threadIdx.x (the fused kernel passes a per-step copy the
+  const int lane = tid & 63;
+  // wave index as a scalar: tile / unit ownership, the divisions t % n, t / n and the ownership branches then run on the
+  // scalar unit instead of the vector pipe
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // tid: threadIdx.x (the fused kernel passes a per-step copy the
   const gsm_rf_params& P = a.rf;                // compiler cannot hoist thread-dependent values out of its step loop with)
   const int bh = sc.bh, bw = sc.bw;
   const int hh = bh / 2, hw = bw / 2;
@@ -174,7 +177,7 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
     // DFT operand tables of this block shape: global -> LDS by LDS-DMA (no registers), in flight during the
     // coefficient phase; whole 1 KiB pieces (128 doubles: the table sizes are multiples of 128 doubles), piece c by
     // wave c mod NW.  The barrier after the coefficient phase drains them.
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int wv = wave;
     const double* gA = a.tables + sc.fy_off;
     for (int c = wv; c < (2 * KR * NR) / 128; c += NW)
       __builtin_amdgcn_global_load_lds(gA + c * 128 + 2 * lane, (__attribute__((address_space(3))) void*)(tabA + c * 128), 16, 0, 0);
