@@ -88,10 +88,11 @@ __device__ __forceinline__ void normals2(uint64_t seed, int64_t step, uint32_t s
   g2 = rad * s;
 }
 
-// 2*pi*fftfreq(n, d=res)[k]
-__device__ __forceinline__ double wavenumber(int k, int n, double res) {
+// 2*pi*fftfreq(n, d=res)[k] with inv = 1 / (n * res): numpy.fft.fftfreq multiplies the integer frequency by that
+// reciprocal too (MCMC.py:221-222), so this is the reference's value and the division happens once per proposal
+__device__ __forceinline__ double wavenumber(int k, int n, double inv) {
   const int kk = (k < (n + 1) / 2) ? k : k - n;  // numpy fftfreq ordering (n even: k=n/2 -> -n/2)
-  return ((double)kk / ((double)n * res)) * 2.0 * M_PI;
+  return ((double)kk * inv) * 2.0 * M_PI;
 }
 
 // Sum over the workgroup of per-tile partials: tile t is reduced by the wave that owns it (fixed lane order, DPP),
@@ -112,8 +113,9 @@ __device__ __forceinline__ double tiles_sum(const double (&part)[16 / (NT / 64)]
 }
 
 // sqrt(S(k)) of MCMC.py:227-239, :244
-__device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const PropScalars& sc, int ky, int kx, int bh, int bw) {
-  const double kxv = wavenumber(kx, bw, P.resolution), kyv = wavenumber(ky, bh, P.resolution);
+__device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const PropScalars& sc, int ky, int kx, int bh, int bw,
+                                              double inv_x, double inv_y) {
+  const double kxv = wavenumber(kx, bw, inv_x), kyv = wavenumber(ky, bh, inv_y);
   const double k = sqrt(kxv * kxv + kyv * kyv) + 1e-10;
   double Sp;
   if (P.model == GSM_MODEL_GAUSSIAN) { const double ak = sc.aa * k; Sp = exp(-0.5 * (ak * ak)); }
@@ -201,6 +203,7 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
       }
     }
     const int nitem = nrow * ncol;
+    const double inv_x = 1.0 / ((double)bw * P.resolution), inv_y = 1.0 / ((double)bh * P.resolution);
     const uint32_t m_nc = pmagic((uint32_t)ncol);
     for (int i = tid; i < nitem && !(a.dbg & 32); i += NT) {
       const int ky = (int)__umulhi((uint32_t)i, m_nc);
@@ -210,7 +213,7 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
       double amp, g1, g2, h1 = 0.0, h2 = 0.0;
       if (a.dbg & 1) { amp = 1.0; g1 = ky; g2 = kx; h1 = 1.0; h2 = 2.0; }
       else {
-        amp = spectral_amp(P, sc, ky, kx, bh, bw);
+        amp = spectral_amp(P, sc, ky, kx, bh, bw, inv_x, inv_y);
         normals2(seed, step, kStreamSpectrum, (uint32_t)(ky * ncol + kx), g1, g2);
         // drawn unconditionally (counter-based: an unused draw costs nothing downstream): one straight-line block for
         // both Box-Muller evaluations, so their polynomial constants are materialised once and the two chains interleave

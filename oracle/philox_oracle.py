@@ -71,7 +71,7 @@ def normals2(seed, step, stream, idx):
 def wavenumber(n, res):
     k = np.arange(n)
     kk = np.where(k < (n + 1) // 2, k, k - n)
-    return (kk / (n * res)) * 2.0 * np.pi
+    return (kk * (1.0 / (n * res))) * 2.0 * np.pi      # = 2 pi numpy.fft.fftfreq(n, d=res): integer frequency x reciprocal
 
 
 def amplitude_half(bh, bw, res, model, range_x, range_y, nu):
