@@ -154,6 +154,10 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       g = g0 + (uint32_t)(qk * W + remk) + (wrap ? (uint32_t)(W - tw) : 0u);
       inwin = valid && (unsigned)(lr - dr) < (unsigned)wh && (unsigned)(lc - dc) < (unsigned)ww;
     };
+    // Cell slot k of this WAVE holds tile cells 64 * wave + 1024 * k ...: past the end of the tile for the later slots of
+    // smaller blocks (on average 2.7 of the 7 slots).  Wave-uniform, so a scalar branch skips the whole slot in the
+    // stencil and commit phases.
+    auto slot_on = [&](int k) { return k * kNT + 64 * wave < ncell; };
     auto relaunder = [&] { asm volatile("" : "+v"(ptid), "+v"(lr0), "+v"(lc0), "+v"(g0)); };
 
     // ---- P: proposal field -> LDS; P0 (inside, after the coefficient phase): chain state of the window -> registers,
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
+        if (!slot_on(k)) { e_new[k] = 0.0; continue; }
         int i, lr, lc; uint32_t g; bool valid, inwin;
         cell(k, i, lr, lc, g, valid, inwin);
         double e = 0.0;
@@ -322,6 +327,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       relaunder();
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
+        if (!slot_on(k)) continue;
         int i, lr, lc; uint32_t g; bool valid, inwin;
         cell(k, i, lr, lc, g, valid, inwin);
         const bool upd = (upd_bits >> k) & 1u;
