@@ -195,6 +195,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     constexpr int KB = (KT > 4) ? 4 : KT;
 #pragma unroll
     for (int kb = 0; kb < KT; kb += KB) {
+      if (kb > 0 && !slot_on(kb)) break;   // this wave has no cell in this sub-batch nor in any later one
       double vf[KB];
       double2 A2[KB], B2[KB];
 #pragma unroll
