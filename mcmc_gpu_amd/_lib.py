@@ -110,14 +110,15 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
+    lib_path = Path(os.environ.get("GSM_LIB", LIB_PATH))   # GSM_LIB: another build of the same ABI (A/B measurements)
+    if not lib_path.exists():
         raise RuntimeError(
-            f"{LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{lib_path} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
     # torch ships its own HIP/HSA runtime.  Import it first so that libgsm_hip's NEEDED libamdhip64.so.7
     # resolves to the runtime torch already loaded -- two HIP runtimes in one process cannot both see the GPU.
     import torch  # noqa: F401
-    lib = C.CDLL(str(LIB_PATH))
+    lib = C.CDLL(str(lib_path))
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     lib.gsm_version.restype = C.c_char_p
     lib.gsm_version.argtypes = []
