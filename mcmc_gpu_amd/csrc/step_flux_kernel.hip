@@ -128,6 +128,9 @@ __global__ __launch_bounds__(kNT, 4) void step_flux_kernel(const StepArgs a) {
       inwin = valid && (unsigned)(lr - dr) < (unsigned)wh && (unsigned)(lc - dc) < (unsigned)ww;
     };
 
+    // cell slot k of this wave is past the end of the tile for the later slots of smaller blocks: wave-uniform skip
+    auto slot_on = [&](int k) { return k * kNT + 64 * wave < ncell; };
+
     // ---- A: loads, candidate bed, fluxes -> LDS, guard, carried energy of the window -----------------
     // in sub-batches of KB cells: all loads of a sub-batch are in flight together (14 VGPRs per cell)
     double v_new[KT];        // candidate bed of the thread's cells
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(kNT, 4) void step_flux_kernel(const StepArgs a) {
     constexpr int KB = (KT > 4) ? 4 : KT;
 #pragma unroll
     for (int kb = 0; kb < KT; kb += KB) {
+      if (kb > 0 && !slot_on(kb)) break;   // no cell of this wave in this sub-batch nor in any later one
       double vb[KB], ve[KB], vf[KB];
       double2 A2[KB], B2[KB];
 #pragma unroll
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(kNT, 4) void step_flux_kernel(const StepArgs a) {
       }
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
+        if (!slot_on(k)) { e_new[k] = 0.0; continue; }
         int i, lr, lc; uint32_t g; bool valid, inwin;
         cell(k, i, lr, lc, g, valid, inwin);
         const int r = hr0 + lr, c = hc0 + lc;
@@ -255,6 +260,7 @@ __global__ __launch_bounds__(kNT, 4) void step_flux_kernel(const StepArgs a) {
       asm volatile("" : "+v"(ptid));
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
+        if (!slot_on(k)) continue;
         int i, lr, lc; uint32_t g; bool valid, inwin;
         cell(k, i, lr, lc, g, valid, inwin);
         const bool upd = (upd_bits >> k) & 1u;
