@@ -6,19 +6,29 @@
 Workload (BASELINE.json configs[1]): 256x256 synthetic grid, 1024 chains per GPU, fp64,
 Matern(0.9125) spectral proposals, blocks 50-80 cells, sigma_mc = 5, Philox draws generated on the device.
 One bench "step" = `--inner` Metropolis steps of every chain = one gsm_run_philox call = one launch of the fused chain
-kernel (proposal + Metropolis step per chain-step inside it; GSM_FUSED=0 selects the older two-kernel pipeline).  Weak scaling: every
-rank runs its own 1024 chains (different seeds), no collective inside the step loop, one all-gather of the
-per-chain caches and an all-reduce of the posterior-mean field at the end of the timed region.
+kernel (proposal + Metropolis step per chain-step inside it).  Weak scaling: every rank runs its own 1024 chains
+(different seeds), no collective inside the step loop, one all-gather of the per-chain caches and an all-reduce of the
+posterior-mean field at the end of the timed region.
+
+Ranks.  Under torchrun (RANK / WORLD_SIZE in the environment) this process is one rank.  Called directly with
+--gpus N > 1 it starts its N ranks ITSELF -- N children of this script, one per GPU, rendezvous on 127.0.0.1 -- before
+anything touches the GPU in the parent, waits for them and exits non-zero if any child failed (the reference's driver
+starts its own workers too, largeScaleChain_multiprocessing_GPU.py:47, :84-85).  Backend "nccl" (= RCCL);
+GSM_DIST_BACKEND=gloo rehearses the same code path with the ranks sharing the visible GPUs.
 
 Prints ONE JSON line on rank 0 (see the driver contract): metric chain-steps/s, plus
-  roofline     -- algorithmic HBM bytes (SURVEY.md 8d formula, summed exactly from the recorded blocks/accepts)
-                  per launch of the dominant kernel / its average duration (HIP events on its own stream)
-  cpu_baseline -- the NumPy oracle (bit-validated restatement of the reference's CPU loop) under the reference's
-                  multiprocessing.Pool pattern on this host's cores, bounded sample, rank 0 at N=1 only.
+  roofline      -- algorithmic HBM bytes (SURVEY.md 8d formula, summed exactly from the recorded blocks/accepts)
+                   per launch of the dominant kernel / its average duration (HIP events on its own stream)
+  cpu_baseline  -- the NumPy oracle (bit-validated restatement of the reference's CPU loop) under the reference's
+                   multiprocessing.Pool pattern on this host's cores, bounded sample, rank 0 at N=1 only
+  other_configs -- (N=1, default workload only) short measurements of BASELINE configs[3] (512x512, precomputed-Cholesky
+                   generator, MFMA roofline) and of one GPU's shard of configs[4] (1024x1024, fp32 state) in the same run.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -34,24 +44,36 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak
 
 
-def pmc_traffic(H, n_chains, steps_per_launch):
-    """HBM-side bytes per launch of the fused chain kernel from the committed rocprofv3 PMC passes
+def pmc_traffic(H, n_chains, state):
+    """HBM-side bytes per chain-step of the fused chain kernel from the COMMITTED rocprofv3 PMC passes
     (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of scripts/pmc_fused.py,
     calibrated on a stream copy of known size, MI355X_MICROARCH.md HBM section), plus the SQ counters of the same
-    workload.  (None, None) when no measurement matches this config."""
+    workload.  Not collected in this run: the returned source string says where the numbers come from.
+    (None, None, None) when no measurement matches this config."""
     try:
         d = json.load(open(ROOT / "profiles" / "pmc_traffic.json"))
-        if (d["grid"], d["chains"], d["steps_per_launch"]) == (H, n_chains, steps_per_launch):
+        if (d["grid"], d["chains"], d.get("state", "f64")) == (H, n_chains, state):
             sq = {k: d[k] for k in ("valu_busy_frac_per_simd", "mfma_busy_frac_per_simd",
-                                    "valu_wave_instructions_per_chain_step", "mfma_instructions_per_chain_step") if k in d}
-            return d["hbm_bytes_per_launch"], sq
+                                    "valu_wave_instructions_per_chain_step", "mfma_instructions_per_chain_step",
+                                    "salu_instructions_per_chain_step") if k in d}
+            per_step = d["hbm_bytes_per_launch"] / (d["chains"] * d["steps_per_launch"])
+            src = f"profiles/pmc_traffic.json @ {d.get('commit', 'round 1')} (rocprofv3 --pmc passes, not collected in this run)"
+            return per_step, sq, src
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
 def algorithmic_bytes(blocks, accept, H, W, state_bytes=8):
-    """s*2*B_eff + a*(s*2*B_eff + 8*B_eff) summed over every chain-step (B_eff = clipped window)."""
+    """s*2*B_eff + a*(s*2*B_eff + 8*B_eff) summed over every chain-step (B_eff = clipped window).
+    NumPy arrays or torch tensors."""
+    if isinstance(blocks, torch.Tensor):
+        row, col, bh, bw = (blocks[..., i].long() for i in range(4))
+        r0 = (row - bh // 2).clamp(min=0); r1 = (row + bh // 2).clamp(max=H)
+        c0 = (col - bw // 2).clamp(min=0); c1 = (col + bw // 2).clamp(max=W)
+        beff = (r1 - r0) * (c1 - c0)
+        a = accept.long()
+        return int((state_bytes * 2 * beff + a * (state_bytes * 2 * beff + 8 * beff)).sum().item())
     row, col, bh, bw = (blocks[..., i].astype(np.int64) for i in range(4))
     r0 = np.maximum(0, row - bh // 2); r1 = np.minimum(H, row + bh // 2)
     c0 = np.maximum(0, col - bw // 2); c1 = np.minimum(W, col + bw // 2)
@@ -105,61 +127,74 @@ def cpu_baseline(H, budget_s=15.0):
             "accept_rate": float(np.mean([r[2] for r in res]))}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--grid", type=int, default=256)
-    ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
-    ap.add_argument("--inner", type=int, default=128, help="Metropolis steps per chain in one bench step")
-    ap.add_argument("--batch", type=int, default=32, help="steps per kernel launch")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
-    ap.add_argument("--gather-beds", action="store_true", help="also all-gather the final beds (512 MiB per GPU at 256^2)")
-    ap.add_argument("--generator", choices=["spectral", "cholesky"], default="spectral",
-                    help="proposal generator: the reference's spectral synthesis (headline) or precomputed Cholesky factors (BASELINE configs[3])")
-    ap.add_argument("--classes", type=int, default=2, help="range classes of the Cholesky generator")
-    ap.add_argument("--state", choices=["f64", "f32"], default="f64",
-                    help="per-chain state storage: f64 (headline) or f32 with f64 arithmetic (BASELINE configs[4])")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
+
+def launch_ranks(n, argv):
+    """Start n ranks of this script (children, one per GPU) and wait.  Runs before anything in this process touches the
+    GPU (torch.cuda.device_count() does not initialise it).  Returns the exit code: 0 only if every rank exited 0."""
+    backend = os.environ.get("GSM_DIST_BACKEND") or ("nccl" if torch.cuda.device_count() > 0 else "gloo")
+    if backend == "nccl" and torch.cuda.device_count() < n:
+        print(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPU(s) visible; RCCL needs one GPU per rank "
+              "(GSM_DIST_BACKEND=gloo rehearses the multi-rank path on fewer)", file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GSM_DIST_BACKEND=backend, GSM_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:          # a dead rank leaves the others waiting in a collective: stop them (exact PIDs)
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def measure(args, H, n_local, generator, state, inner, batch, steps, warmup, rank, world, dev, classes=2, headline=True):
+    """One workload, timed as the driver contract says; returns the result dict (rank 0) or None."""
     from mcmc_gpu_amd import parallel, synthetic
-    rank, local_rank, world = parallel.dist_env()
-    cpu_res = None
-    if world == 1 and not args.no_cpu_baseline:
-        cpu_res = cpu_baseline(args.grid, args.cpu_budget)   # before the GPU is initialised: the pool forks
-    rank, local_rank, world = parallel.init_distributed()
-    if world != args.gpus and rank == 0:
-        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    dev_index = local_rank if torch.cuda.device_count() > local_rank else 0
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-
-    H = args.grid
-    n_local = args.chains
+    dev_index = dev.index
     n_total = n_local * world
     prob, ch, rf = synthetic.template(H)
-    ch.state_dtype = args.state
-    beds0 = synthetic.initial_beds(prob, n_local, first=rank * n_local)
+    ch.state_dtype = state
+    sbytes = 8 if state == "f64" else 4
+    if headline:
+        beds0 = synthetic.initial_beds(prob, n_local, first=rank * n_local)   # SURVEY 8d initial beds, chain by chain
+    else:
+        g = torch.Generator(device=dev); g.manual_seed(1000 + rank)
+        beds0 = torch.as_tensor(prob["bed"], device=dev)[None] + 5.0 * torch.randn((n_local, H, H), dtype=torch.float64, device=dev, generator=g)
     seeds = [7 + rank * n_local + i for i in range(n_local)]
     eng = ch._make_engine(rf, n_local, dev_index)
     eng.set_state(beds0)
     del beds0
     eng.enable_timing(True)
-    if args.generator == "cholesky":
+    t_setup = time.perf_counter()
+    if generator == "cholesky":
         from mcmc_gpu_amd import cholesky as chol
         rf.generator = "cholesky"
-        chol.build_factors(eng, rf, n_classes=args.classes)
+        chol.build_factors(eng, rf, n_classes=classes)
+    t_setup = time.perf_counter() - t_setup
     p = eng.rf_struct(rf)
-    inner, batch = args.inner, args.batch
-    n_timed = args.steps * inner
+    n_timed = steps * inner
     loss = torch.empty((n_local, inner), dtype=torch.float64, device=dev)
     acc = torch.empty((n_local, inner), dtype=torch.uint8, device=dev)
     blk = torch.empty((n_local, inner, 4), dtype=torch.int32, device=dev)
     acc_all = torch.empty((n_local, n_timed), dtype=torch.uint8, device=dev)
     loss_all = torch.empty((n_local, n_timed), dtype=torch.float64, device=dev)
-    blk_all = torch.empty((n_local, n_timed, 4), dtype=torch.int32, device=dev)
 
     def segment_end():
         """Per-chain caches to every rank, posterior-mean field, small results to the host."""
@@ -171,23 +206,30 @@ def main():
         return g_loss[:, -1].cpu(), float(g_acc.float().mean().item()), mean_field.cpu()
 
     step0 = 0
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         eng.run_philox(inner, step0, seeds, p, batch=batch, out=(loss, acc, blk), to_host=False)
         step0 += inner
-    if args.warmup > 0:
+    if warmup > 0:
         acc_all.zero_(); loss_all.zero_()
         segment_end()          # loads torch's reduce/copy kernels and RCCL channels outside the timed region
+        algorithmic_bytes(blk, acc, H, H, sbytes)
     torch.cuda.synchronize(dev)
     parallel.barrier()
     torch.cuda.synchronize(dev)
     t_step = t_prop = 0.0
     n_step_l = n_prop_l = 0
+    bytes_total = 0
+    flops_total = 0.0
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         eng.run_philox(inner, step0, seeds, p, batch=batch, out=(loss, acc, blk), to_host=False)
         step0 += inner
         sl = slice(k * inner, (k + 1) * inner)
-        acc_all[:, sl] = acc; loss_all[:, sl] = loss; blk_all[:, sl] = blk
+        acc_all[:, sl] = acc; loss_all[:, sl] = loss
+        if rank == 0:    # bookkeeping of the roofline numerator (device-side reduction of this step's records)
+            bytes_total += algorithmic_bytes(blk, acc, H, H, sbytes)
+            if generator == "cholesky":
+                flops_total += float(((blk[..., 2].double() * blk[..., 3].double()) ** 2).sum().item())
         tm = eng.last_timing()
         t_step += tm["step_ms"] * tm["step_launches"]; n_step_l += tm["step_launches"]
         t_prop += tm["proposal_ms"] * tm["proposal_launches"]; n_prop_l += tm["proposal_launches"]
@@ -196,97 +238,140 @@ def main():
     parallel.barrier()
     torch.cuda.synchronize(dev)
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
-
-    # two-kernel pipeline only (GSM_FUSED=0): the kernels co-run on two streams in the timed region, which stretches each
-    # one's duration; time one launch of each ALONE as well (outside the timed region) so the roofline can be read both ways
-    iso = None
-    fused = args.generator == "spectral" and os.environ.get("GSM_FUSED", "1") != "0"
-    if args.generator == "spectral" and not fused:
-        import ctypes as C
-        from mcmc_gpu_amd.engine import _ptr
-        nrec = n_local * batch
-        t_si = torch.empty(nrec, dtype=torch.int32, device=dev); t_ce = torch.empty(2 * nrec, dtype=torch.int32, device=dev)
-        t_u = torch.empty(nrec, dtype=torch.float64, device=dev)
-        t_f = torch.empty((nrec, eng.field_stride), dtype=torch.float64, device=dev)
-        t_l = torch.empty(nrec, dtype=torch.float64, device=dev); t_a = torch.empty(nrec, dtype=torch.uint8, device=dev)
-        d_seeds = eng._seeds(seeds)
-        tp, ts, ab = [], [], []
-        for r in range(3):
-            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-            e0.record()
-            eng._check(eng.lib.gsm_propose_philox(eng.h, batch, step0 + r * batch, _ptr(d_seeds), C.byref(p), _ptr(t_si), _ptr(t_ce),
-                                                  _ptr(t_u), _ptr(t_f), eng.field_stride, None, eng._stream()))
-            e1.record()
-            eng._check(eng.lib.gsm_run_replay(eng.h, batch, _ptr(eng.beds), _ptr(eng.energy), _ptr(eng.resampled), _ptr(eng.loss_sum),
-                                              _ptr(t_si), _ptr(t_ce), _ptr(t_u), _ptr(t_f), eng.field_stride, _ptr(t_l), _ptr(t_a),
-                                              eng._stream()))
-            e2.record(); torch.cuda.synchronize(dev)
-            tp.append(e0.elapsed_time(e1)); ts.append(e1.elapsed_time(e2))
-            si_h = t_si.cpu().numpy()
-            b_h = np.concatenate([t_ce.view(n_local, batch, 2).cpu().numpy(), eng.bh[si_h].reshape(n_local, batch, 1),
-                                  eng.bw[si_h].reshape(n_local, batch, 1)], axis=2)
-            ab.append(algorithmic_bytes(b_h, t_a.view(n_local, batch).cpu().numpy(), H, H, 8 if args.state == "f64" else 4))
-        iso = {"step_kernel_ms": float(np.median(ts)), "propose_kernel_ms": float(np.median(tp)), "bytes_per_launch": float(np.mean(ab))}
-        del t_f
+    fused = bool(eng.last_run_fused())
+    eng.close()
+    if rank != 0:
+        return None
 
     chain_steps = n_total * n_timed
-    value = chain_steps / elapsed
-    if rank == 0:
-        blocks_h = blk_all.cpu().numpy(); acc_h = acc_all.cpu().numpy()
-        bytes_total = algorithmic_bytes(blocks_h, acc_h, H, H, 8 if args.state == "f64" else 4)
-        bytes_per_launch = bytes_total / max(n_step_l, 1)
-        step_ms = t_step / max(n_step_l, 1); prop_ms = t_prop / max(n_prop_l, 1)
-        dom = "step_kernel" if t_step >= t_prop else "propose_kernel"
-        if fused:
-            dom = "chain_fused_kernel"
+    bytes_per_launch = bytes_total / max(n_step_l, 1)
+    step_ms = t_step / max(n_step_l, 1); prop_ms = t_prop / max(n_prop_l, 1)
+    steps_per_launch = n_timed / max(n_step_l, 1)
+    if generator == "cholesky":
+        # algorithmic flops per chain-step = (bh*bw)^2 (lower-triangular L z)
+        flops_per_launch = flops_total / max(n_prop_l, 1)
+        ach = flops_per_launch / (prop_ms * 1e-3) / 1e12 if prop_ms > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / MFMA_F64_PEAK_TFLOPS, "traffic": None, "kernel": "cz_* proposal pipeline (zgen + gemm)",
+                "algorithmic_flops_per_chain_step": flops_total / (n_local * n_timed), "flops_per_launch": flops_per_launch,
+                "step_kernel_ms": step_ms, "propose_kernel_ms": prop_ms, "launches": n_prop_l}
+    else:
+        dom = "chain_fused_kernel" if fused else ("step_kernel" if t_step >= t_prop else "propose_kernel")
         dom_ms = prop_ms if dom == "propose_kernel" else step_ms
         achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic, sq = pmc_traffic(H, n_local, inner) if fused else (None, None)
+        per_step, sq, src = pmc_traffic(H, n_local, state) if fused else (None, None, None)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
-                "algorithmic_bytes_per_chain_step": bytes_total / (n_local * n_timed),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": per_step * n_local * steps_per_launch if per_step else None,
+                "kernel": dom, "algorithmic_bytes_per_chain_step": bytes_total / (n_local * n_timed),
                 "bytes_per_launch": bytes_per_launch, "kernel_ms": dom_ms, "launches": n_step_l}
-        if fused:
-            # what actually limits the fused kernel: fp64 VALU issue (Philox + Box-Muller + spectral amplitude + index
-            # math) with the fp64 matrix pipe on the same datapath -- rocprofv3 SQ counters of the same workload
-            if sq:
-                roof["issue_limits"] = sq
-        else:
+        if per_step:
+            roof["traffic_source"] = src
+        if sq:
+            # what actually limits the fused kernel: vector-instruction issue (rocprofv3 SQ counters of the same workload)
+            roof["issue_limits"] = dict(sq, source=src)
+        if not fused:
             roof["step_kernel_ms"] = step_ms; roof["propose_kernel_ms"] = prop_ms
-        if iso is not None:
-            for k in ("step_kernel", "propose_kernel"):
-                iso[k + "_frac"] = iso["bytes_per_launch"] / (iso[k + "_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-            iso["note"] = "one launch of each kernel alone on an idle GPU (torch events), outside the timed region"
-            roof["isolated"] = iso
-        if args.generator == "cholesky":
-            # algorithmic flops per chain-step = (bh*bw)^2 (lower-triangular L z)
-            nn = (blocks_h[..., 2].astype(np.float64) * blocks_h[..., 3]) ** 2
-            flops_per_launch = float(nn.sum()) / max(n_prop_l, 1)
-            ach = flops_per_launch / (prop_ms * 1e-3) / 1e12 if prop_ms > 0 else 0.0
-            roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / MFMA_F64_PEAK_TFLOPS, "traffic": None, "kernel": "cz_* proposal pipeline (zgen + gemm)",
-                    "algorithmic_flops_per_chain_step": float(nn.mean()), "flops_per_launch": flops_per_launch,
-                    "step_kernel_ms": step_ms, "propose_kernel_ms": prop_ms, "launches": n_prop_l}
-        out = {
-            "metric": "chain-steps/sec on 256x256 grid x 1024 chains; accept-rate parity",
-            "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64" if args.state == "f64" else "f64 arithmetic on f32 state", "data": "synthetic",
-            "config": {"workload": f"largeScaleChain {H}x{H} grid, {n_local} chains/GPU, {'fp64' if args.state == 'f64' else 'fp32 state / fp64 arithmetic'}, Philox "
-                                   + ("spectral (Matern 0.9125) proposals, blocks 50-80, sigma_mc 5 "
-                                      + ("(BASELINE configs[1])" if args.state == "f64" else "(BASELINE configs[4], one GPU's shard)")
-                                      if args.generator == "spectral" else
-                                      f"precomputed-Cholesky (Matern 0.9125, {args.classes} range classes) proposals, "
-                                      "blocks 50-80, sigma_mc 5 (BASELINE configs[3])"),
-                       "chains_total": n_total, "mh_steps_per_bench_step": inner,
-                       "steps_per_launch": inner if fused else batch},
-            "accept_rate": h_acc_rate, "final_loss_mean": float(h_loss.mean()),
-            "roofline": roof,
-        }
+    gen_txt = ("spectral (Matern 0.9125) proposals" if generator == "spectral" else
+               f"precomputed-Cholesky (Matern 0.9125, {classes} range classes) proposals")
+    tag = {("spectral", "f64", 256): "BASELINE configs[1]" if world == 1 else "BASELINE configs[2] at 8 GPUs: 1024 chains/GPU",
+           ("cholesky", "f64", 512): "BASELINE configs[3]",
+           ("spectral", "f32", 1024): "BASELINE configs[4], one GPU's shard"}.get((generator, state, H), "")
+    return {
+        "metric": f"chain-steps/sec on {H}x{H} grid x {n_local} chains{' per GPU' if world > 1 else ''}; accept-rate parity",
+        "value": chain_steps / elapsed, "unit": "chain-steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64" if state == "f64" else "f64 arithmetic on f32 state", "data": "synthetic",
+        "config": {"workload": f"largeScaleChain {H}x{H} grid, {n_local} chains/GPU, "
+                               f"{'fp64' if state == 'f64' else 'fp32 state / fp64 arithmetic'}, Philox {gen_txt}, blocks 50-80, "
+                               f"sigma_mc 5" + (f" ({tag})" if tag else ""),
+                   "chains_total": n_total, "mh_steps_per_bench_step": inner, "steps_per_launch": steps_per_launch,
+                   "timed_seconds": elapsed, "setup_seconds_factors": t_setup if generator == "cholesky" else None},
+        "accept_rate": h_acc_rate, "final_loss_mean": float(h_loss.mean()),
+        "roofline": roof,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
+    ap.add_argument("--inner", type=int, default=2048,
+                    help="Metropolis steps per chain in one bench step (2048: --steps 20 times several seconds)")
+    ap.add_argument("--batch", type=int, default=32, help="steps per kernel launch of the two-kernel pipeline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[3] / configs[4]-shard lines")
+    ap.add_argument("--gather-beds", action="store_true", help="also all-gather the final beds (512 MiB per GPU at 256^2)")
+    ap.add_argument("--generator", choices=["spectral", "cholesky"], default="spectral",
+                    help="proposal generator: the reference's spectral synthesis (headline) or precomputed Cholesky factors (BASELINE configs[3])")
+    ap.add_argument("--classes", type=int, default=2, help="range classes of the Cholesky generator")
+    ap.add_argument("--state", choices=["f64", "f32"], default="f64",
+                    help="per-chain state storage: f64 (headline) or f32 with f64 arithmetic (BASELINE configs[4])")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous, barrier and max-over-ranks only (no GPU work): checks that --gpus N starts N ranks")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))       # nothing above touched the GPU
+
+    from mcmc_gpu_amd import parallel
+    rank, local_rank, world = parallel.dist_env()
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+              "(or without a launcher: bench.py starts its own ranks)", file=sys.stderr)
+        sys.exit(2)
+    if args.launch_check:
+        parallel.init_distributed()
+        parallel.barrier()
+        nccl = world > 1 and torch.distributed.get_backend() == "nccl"
+        tmax = parallel.max_over_ranks(float(rank), torch.device("cuda", local_rank) if nccl else torch.device("cpu"))
+        ws = torch.distributed.get_world_size() if world > 1 else 1
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "world_size": ws, "max_rank_seen": tmax,
+                              "backend": torch.distributed.get_backend() if world > 1 else None}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    default_workload = (args.grid, args.chains, args.generator, args.state) == (256, 1024, "spectral", "f64")
+    cpu_res = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu_res = cpu_baseline(args.grid, args.cpu_budget)   # before the GPU is initialised: the pool forks
+    rank, local_rank, world = parallel.init_distributed()
+    dev_index = local_rank if torch.cuda.device_count() > local_rank else 0
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+
+    inner = args.inner if args.generator == "spectral" else min(args.inner, 128)
+    out = measure(args, args.grid, args.chains, args.generator, args.state, inner, args.batch, args.steps, args.warmup,
+                  rank, world, dev, classes=args.classes)
+    if rank == 0:
+        out["world_size"] = torch.distributed.get_world_size() if world > 1 else 1
+        out["launcher"] = "self" if os.environ.get("GSM_BENCH_SELF_LAUNCHED") else ("torchrun" if world > 1 else "single process")
+        if world > 1:
+            out["backend"] = torch.distributed.get_backend()
         if cpu_res is not None:
             out["cpu_baseline"] = cpu_res
+    if world == 1 and default_workload and not args.no_extras:
+        extras = {}
+        for name, kw in (("configs[3]", dict(H=512, n_local=1024, generator="cholesky", state="f64", inner=128, batch=32, steps=3, warmup=1)),
+                         ("configs[4] one GPU's shard", dict(H=1024, n_local=512, generator="spectral", state="f32", inner=512, batch=32, steps=3, warmup=1))):
+            t0 = time.perf_counter()
+            try:
+                r = measure(args, rank=rank, world=world, dev=dev, classes=2, headline=False, **kw)
+                r["wall_seconds_incl_setup"] = time.perf_counter() - t0
+                extras[name] = r
+            except Exception as e:      # the headline line must not be lost to a failure here; the failure is reported
+                extras[name] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+        out["other_configs"] = extras
+    if rank == 0:
         print(json.dumps(out))
-    eng.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

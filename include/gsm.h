@@ -67,7 +67,8 @@ typedef struct {
   int32_t reserved;
 } gsm_vario;
 
-/* Library / build identification: "gsm-hip <version> gfx950". */
+/* Library / build identification: "gsm-hip <version> gfx950 src:<hash>", hash = first 16 hex digits of the SHA-256 of the
+ * library sources at build time (the Python loader checks it against the sources it sees). */
 const char* gsm_version(void);
 
 /* Text of the last error on this handle (or of the last failed gsm_create when h is NULL). */
@@ -147,24 +148,41 @@ int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, const uint6
                        const gsm_rf_params* rf, int32_t* size_idx, int32_t* centre, double* u,
                        double* fields, int64_t field_stride, double* rf_scalars, void* stream);
 
-/* Philox mode end to end.  Spectral generator: one launch of the fused chain kernel (per chain-step the proposal is
- * generated and consumed inside one workgroup; nothing but chain state touches HBM; `batch` is not used).  Cholesky
- * generator, block tables beyond the fused kernel's LDS budget, or GSM_FUSED=0 in the environment: batches of `batch`
- * steps, proposals of batch k+1 generated on a second stream while batch k is stepped, scratch owned by the handle.
- * Both forms give bit-identical results.  Outputs as gsm_run_replay plus blocks [dev, n_chains*n_steps*4]
- * = (row, col, bh, bw) (blocks_cache, MCMC.py:1264).  Synchronises the stream before returning.
+/* The spectral synthesis alone, fed with CALLER-SUPPLIED white noise instead of Philox draws: the value pin of the device
+ * arithmetic against the reference's.  For field r of n_fields:
+ *   size_idx   [dev, n_fields]                 block-table index -> shape (bh, bw)
+ *   rf_scalars [dev, n_fields*4]               (scale, nugget, range_x, range_y): `scale` is the value multiplied in at
+ *                                              MCMC.py:251 (already / 3), ranges as drawn at MCMC.py:204-207
+ *   noise_re, noise_im [dev]                   the two rng.normal(size=(bh, bw)) planes of MCMC.py:242, row-major at
+ *                                              r*field_stride doubles
+ *   nugget_field [dev] (may be NULL)           rng.normal(0, sqrt(nug), size=(bh, bw)) of MCMC.py:251, same layout
+ * The library forms the Hermitian half Zh[k] = sqrt(S(k)) ((N1[k] + N1[-k])/2 + i (N2[k] - N2[-k])/2) -- Re(ifft2(Z)) is
+ * the inverse DFT of the Hermitian part of Z -- and then runs EXACTLY the code of gsm_propose_philox / the fused kernel
+ * on it: spectral amplitude, folded matrix-core inverse DFT, standardisation, scale, nugget, edge mask (MCMC.py:221-251,
+ * :778).  fields [dev] receives f * edge_mask at r*field_stride.
+ * Replaces: spectral_synthesis_field (MCMC.py:176-254) for given draws. */
+int gsm_spectral_from_noise(gsm_handle h, int32_t n_fields, const int32_t* size_idx, const double* rf_scalars,
+                            const gsm_rf_params* rf, const double* noise_re, const double* noise_im,
+                            const double* nugget_field, double* fields, int64_t field_stride, void* stream);
+
+/* Philox mode end to end.  Spectral generator: the fused chain kernel (per chain-step the proposal is generated and
+ * consumed inside one workgroup; nothing but chain state touches HBM), launched once per segment of at most 4096 steps
+ * (scratch: one 124-byte scalar record per chain and step of a SEGMENT; `batch` is not used).  Cholesky generator, block
+ * tables beyond the fused kernel's LDS budget, or GSM_FUSED=0 in the environment: batches of `batch` steps, proposals of
+ * batch k+1 generated on a second stream while batch k is stepped, scratch owned by the handle.
+ * Both forms give bit-identical results, whatever the segment / batch size.  Outputs as gsm_run_replay plus blocks
+ * [dev, n_chains*n_steps*4] = (row, col, bh, bw) (blocks_cache, MCMC.py:1264).  Synchronises the stream before returning.
  * Replaces: chain_crf.run for a whole shard of chains (MCMC.py:1137-1443) as called from
  * lsc_run_wrapper (largeScaleChain_multiprocessing_GPU.py:194-201). */
 int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int32_t batch, const uint64_t* seeds,
                    const gsm_rf_params* rf, void* beds, void* energy, uint32_t* resampled, double* loss_sum,
                    double* loss, uint8_t* accept, int32_t* blocks, void* stream);
 
-/* Select the launch structure of gsm_run_philox for the spectral generator on this handle: 1 = fused chain kernel, one
- * 1024-thread workgroup per CU (default); 2 = fused chain kernel, two 512-thread workgroups per CU; 0 = two-kernel
- * pipeline.  Identical results; kept for A/B measurements and tests.  Environment default: GSM_FUSED. */
+/* Select the launch structure of gsm_run_philox for the spectral generator on this handle: 1 = fused chain kernel
+ * (default), 0 = two-kernel pipeline.  Identical results; kept for A/B measurements and tests.  Environment default:
+ * GSM_FUSED. */
 int gsm_set_fused(gsm_handle h, int32_t on);
-/* Which form the last gsm_run_philox call on this handle ran: 1 / 2 = fused chain kernel (1024 / 512 threads), 0 = the
- * two-kernel pipeline. */
+/* Which form the last gsm_run_philox call on this handle ran: 1 = fused chain kernel, 0 = the two-kernel pipeline. */
 int gsm_last_run_fused(gsm_handle h);
 
 /* Average duration in milliseconds of the step kernel / the proposal kernel over the launches made

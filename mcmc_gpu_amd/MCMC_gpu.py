@@ -33,22 +33,25 @@ __all__ = ["RandField", "chain_crf_gpu", "init_lsc_chain_by_instance", "initiate
            "spectral_synthesis_field", "run_many", "min_dist_from_mask"]
 
 
-def min_dist_from_mask(xx, yy, mask, device=True):
-    """Distance from every cell to the nearest True cell of `mask` (Utilities.py:21-24).  On a machine with a GPU the
-    exact brute-force HIP kernel is used (gsm_min_dist_from_mask); the host KD-tree (what the reference calls) is the
-    setup-time path elsewhere.  Both give the same values (test_min_dist_device_equals_kdtree)."""
+def min_dist_from_mask(xx, yy, mask, device=None):
+    """Distance from every cell to the nearest True cell of `mask` (Utilities.py:21-24) -- SETUP-time code, run once per
+    problem, not part of the sampler's hot path.
+    device=True: the exact brute-force HIP kernel (gsm_min_dist_from_mask); raises without a GPU.
+    device=False: the host KD-tree query, which is literally what the reference calls at this point (scipy, not the oracle).
+    device=None (default): the HIP kernel when a GPU is visible, else the host KD-tree -- so that chain / RandField objects
+    can be SET UP (and pickled, and handed to workers) on a machine without a GPU, as the reference's driver does before it
+    starts its pool.  Both give the same values bit for bit (test_min_dist_device_equals_kdtree).  The sampler itself
+    (chain_crf_gpu.run, run_many) has no host fallback."""
+    if device is None:
+        import torch
+        device = torch.cuda.is_available()
     if device:
+        from .engine import GsmEngine
+        eng = GsmEngine(xx.shape[0], xx.shape[1], 1)      # raises RuntimeError without a GPU
         try:
-            import torch
-            if torch.cuda.is_available():
-                from .engine import GsmEngine
-                eng = GsmEngine(xx.shape[0], xx.shape[1], 1)
-                try:
-                    return eng.min_dist_from_mask(xx, yy, mask)
-                finally:
-                    eng.close()
-        except ImportError:
-            pass
+            return eng.min_dist_from_mask(xx, yy, mask)
+        finally:
+            eng.close()
     from scipy.spatial import cKDTree
     pts = np.array([xx[mask], yy[mask]]).T
     if pts.shape[0] == 0:

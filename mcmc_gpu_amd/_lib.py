@@ -16,14 +16,13 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libgsm_hip.so"
 HEADER = PKG_DIR.parent / "include" / "gsm.h"
-SOURCES = ["gsm_api.hip", "step_kernel.hip", "step_flux_kernel.hip", "chain_fused_kernel.hip", "chain_fused512_kernel.hip", "proposal_kernel.hip", "cholesky_kernel.hip"]
+SOURCES = ["gsm_api.hip", "gsm_version.hip", "step_kernel.hip", "step_flux_kernel.hip", "chain_fused_kernel.hip", "proposal_kernel.hip", "cholesky_kernel.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-Wno-unused-value", "-Wno-unused-result"]
 # per-file extras.  step_flux_kernel: without machine LICM the fp64 polynomial constants of exp() are materialised at
 # their use instead of being hoisted out of the step loop into ~30 VGPRs that are then spilled.
 EXTRA_FLAGS = {"step_flux_kernel.hip": ["-mllvm", "-disable-machine-licm"],
-               "chain_fused_kernel.hip": ["-mllvm", "-disable-machine-licm"],
-               "chain_fused512_kernel.hip": ["-mllvm", "-disable-machine-licm"]}
+               "chain_fused_kernel.hip": ["-mllvm", "-disable-machine-licm"]}
 OBJ_DIR = PKG_DIR / "_build"
 
 
@@ -35,12 +34,26 @@ class GsmError(RuntimeError):
         self.code = code
 
 
+def source_hash() -> str:
+    """First 16 hex digits of the SHA-256 over the library sources (csrc/*.hip, csrc/*.h, include/gsm.h, by name)."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")), key=lambda q: q.name) + [HEADER]:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def built_hash(path: Path = LIB_PATH):
+    """The source hash embedded in a built library (gsm_version's "src:<hash>"), read from the file without loading it."""
+    if not path.exists():
+        return None
+    m = re.search(rb"gsm-hip [0-9.]+ gfx950 src:([0-9a-f]{16})", path.read_bytes())
+    return m.group(1).decode() if m else None
+
+
 def _stale() -> bool:
-    if not LIB_PATH.exists():
-        return True
-    t = LIB_PATH.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + list(CSRC.glob("*.h")) + [HEADER]
-    return any(p.stat().st_mtime > t for p in deps if p.exists())
+    return built_hash() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
@@ -51,14 +64,18 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libgsm_hip.so")
     OBJ_DIR.mkdir(exist_ok=True)
+    src_hash = source_hash()
     hdr_t = max(p.stat().st_mtime for p in list(CSRC.glob("*.h")) + [HEADER])
     procs, objs = [], []
     for s in SOURCES:
         src, obj = CSRC / s, OBJ_DIR / (s + ".o")
         objs.append(str(obj))
-        if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_t):
+        is_version = s == "gsm_version.hip"
+        if not force and not is_version and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_t):
             continue
         diag = ["-DGSM_STAMPS"] if os.environ.get("GSM_STAMPS") else []
+        if is_version:
+            diag.append(f'-DGSM_SRC_HASH="{src_hash}"')
         cmd = [hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(s, []), *diag, "-c", "-o", str(obj), str(src)]
         if verbose:
             print(" ".join(cmd))
@@ -118,6 +135,13 @@ def load() -> C.CDLL:
     # torch ships its own HIP/HSA runtime.  Import it first so that libgsm_hip's NEEDED libamdhip64.so.7
     # resolves to the runtime torch already loaded -- two HIP runtimes in one process cannot both see the GPU.
     import torch  # noqa: F401
+    if "GSM_LIB" not in os.environ and built_hash(lib_path) != source_hash():
+        # the binary is git-ignored and travels prebuilt: never run kernels that are not the sources' 
+        if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+            build()
+        if built_hash(lib_path) != source_hash():
+            raise RuntimeError(f"{lib_path} was built from other sources (embedded hash {built_hash(lib_path)}, sources "
+                               f"{source_hash()}): rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
     lib = C.CDLL(str(lib_path))
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     lib.gsm_version.restype = C.c_char_p
@@ -133,6 +157,7 @@ def load() -> C.CDLL:
     lib.gsm_residual.argtypes = [vp, vp, vp, vp]
     lib.gsm_run_replay.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]
     lib.gsm_propose_philox.argtypes = [vp, i32, i64, vp, C.POINTER(RfParams), vp, vp, vp, vp, i64, vp, vp]
+    lib.gsm_spectral_from_noise.argtypes = [vp, i32, vp, vp, C.POINTER(RfParams), vp, vp, vp, vp, i64, vp]
     lib.gsm_run_philox.argtypes = [vp, i32, i64, i32, vp, C.POINTER(RfParams), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsm_enable_timing.argtypes = [vp, i32]
     lib.gsm_set_fused.argtypes = [vp, i32]

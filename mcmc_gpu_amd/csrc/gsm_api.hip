@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
 
 using namespace gsm;
@@ -57,6 +58,7 @@ struct gsm_context {
 };
 
 static thread_local std::string g_create_err;
+static constexpr int kFusedSegment = 4096;   // steps per launch of the fused chain kernel
 
 static int fail(gsm_handle h, int code, const std::string& msg) {
   if (h) h->err = msg; else g_create_err = msg;
@@ -68,8 +70,6 @@ static int fail(gsm_handle h, int code, const std::string& msg) {
     if (_e != hipSuccess)                                                                     \
       return fail(h, GSM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
   } while (0)
-
-extern "C" const char* gsm_version(void) { return "gsm-hip 0.1 gfx950"; }
 
 extern "C" const char* gsm_last_error(gsm_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
@@ -457,11 +457,42 @@ extern "C" int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, 
   return GSM_OK;
 }
 
+extern "C" int gsm_spectral_from_noise(gsm_handle h, int32_t n_fields, const int32_t* size_idx, const double* rf_scalars,
+                                       const gsm_rf_params* rf, const double* noise_re, const double* noise_im,
+                                       const double* nugget_field, double* fields, int64_t field_stride, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!h->have_blocks || !h->d_masks) return fail(h, GSM_E_STATE, "gsm_spectral_from_noise: call gsm_set_blocks with edge masks first");
+  if (!rf) return fail(h, GSM_E_ARG, "gsm_spectral_from_noise: rf is NULL");
+  gsm_rf_params rfs = *rf;
+  rfs.generator = GSM_GEN_SPECTRAL;
+  const bool had_centres = h->have_centres;
+  h->have_centres = true;                      // no centre is drawn here
+  int rc = check_propose_ready(h, &rfs, "gsm_spectral_from_noise");
+  h->have_centres = had_centres;
+  if (rc) return rc;
+  if (n_fields < 1 || n_fields > (1 << 20)) return fail(h, GSM_E_ARG, "gsm_spectral_from_noise: n_fields must be in [1, 2^20]");
+  if (!size_idx || !rf_scalars || !noise_re || !noise_im || !fields) return fail(h, GSM_E_ARG, "gsm_spectral_from_noise: NULL pointer");
+  if (field_stride < (int64_t)h->B.max_bh * h->B.max_bw) return fail(h, GSM_E_ARG, "gsm_spectral_from_noise: field_stride too small");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<int32_t> si((size_t)n_fields);
+  HIPCHK(h, hipMemcpyAsync(si.data(), size_idx, sizeof(int32_t) * (size_t)n_fields, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  for (int32_t v : si)
+    if (v < 0 || v >= h->B.n_sizes) return fail(h, GSM_E_DEVICE_DATA, "gsm_spectral_from_noise: size index out of range");
+  { int rc2 = ensure_scalars(h, 0, (size_t)n_fields); if (rc2) return rc2; }
+  ProposeArgs p = make_propose(h, &rfs, n_fields, 0, nullptr);
+  p.n_chains = 1;
+  p.fields = fields; p.field_stride = field_stride; p.scalars = h->d_scalars[0];
+  HIPCHK(h, launch_spectral_from_noise(p, size_idx, rf_scalars, noise_re, noise_im, nugget_field, st));
+  return GSM_OK;
+}
+
 extern "C" int gsm_last_run_fused(gsm_handle h) { return h ? h->last_fused : GSM_E_ARG; }
 
 extern "C" int gsm_set_fused(gsm_handle h, int32_t on) {
   if (!h) return GSM_E_ARG;
-  h->use_fused = (on == 2) ? 2 : (on ? 1 : 0);
+  h->use_fused = on ? 1 : 0;
   return GSM_OK;
 }
 
@@ -500,23 +531,26 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
   if (h->use_fused < 0) { const char* v = getenv("GSM_FUSED"); h->use_fused = v ? atoi(v) : 1; }
   h->last_fused = 0;
   if (h->use_fused && rf->generator == GSM_GEN_SPECTRAL) {
+    // Segments of at most kFusedSegment steps: the per-(chain, step) scalar records (104 + 20 bytes) are sized by the
+    // segment, not by the call, and a long call is a sequence of bounded launches on the caller's stream.  Counters are
+    // functions of the absolute step, so the split is invisible in the results (test_fused_internal_segments...).
+    int seg_cap = kFusedSegment;
+    if (const char* v = getenv("GSM_FUSED_SEGMENT")) { const int q = atoi(v); if (q >= 1) seg_cap = q; }
+    const int seg_max = std::min(n_steps, seg_cap);
     FusedArgs fa{};
     StepArgs& a = fa.T;
     a.S = h->S; a.B = h->B;
-    a.n_chains = h->n_chains; a.n_steps = n_steps; a.tile_cap = h->tile_cap;
+    a.n_chains = h->n_chains; a.n_steps = seg_max; a.tile_cap = h->tile_cap;
     a.beds = beds; a.energy = energy; a.f32_state = h->f32_state; a.resampled = resampled; a.loss_sum = loss_sum;
     a.loss = loss; a.accept = accept; a.blocks = blocks;
-    a.rec_stride = n_steps; a.rec_offset = 0; a.in_stride = n_steps;
+    a.rec_stride = n_steps; a.rec_offset = 0; a.in_stride = seg_max;
     a.err_flag = h->d_err;
-    { int rc2 = ensure_scalars(h, 0, (size_t)h->n_chains * n_steps); if (rc2) return rc2; }
-    fa.P = make_propose(h, rf, n_steps, step0, seeds);
-    fa.P.scalars = h->d_scalars[0];
-    // the scalars kernel also writes (size_idx, centre, u) records: give it the scalar-sized scratch of slot 1
-    h->last_fused = 0;
-    const bool want512 = h->use_fused == 2 && fused512_supported(fa);
-    if (want512 || fused_supported(fa)) {
-      h->last_fused = want512 ? 2 : 1;
-      const size_t recs1 = (size_t)h->n_chains * n_steps;
+    fa.P = make_propose(h, rf, seg_max, step0, seeds);
+    if (fused_supported(fa)) {
+      h->last_fused = 1;
+      const size_t recs1 = (size_t)h->n_chains * seg_max;
+      { int rc2 = ensure_scalars(h, 0, recs1); if (rc2) return rc2; }
+      // the scalars kernel also writes (size_idx, centre, u) records: give it the scalar-sized scratch of slot 1
       auto& sc = h->scr[1];
       if (sc.recs < recs1 || sc.fields) {
         if (sc.size_idx) { hipFree(sc.size_idx); hipFree(sc.centre); hipFree(sc.u); if (sc.fields) hipFree(sc.fields); sc = gsm_context::Scratch(); }
@@ -525,20 +559,29 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
         HIPCHK(h, hipMalloc(&sc.u, recs1 * sizeof(double)));
         sc.recs = recs1;
       }
-      fa.P.size_idx = sc.size_idx; fa.P.centre = sc.centre; fa.P.u = sc.u;
-      hipEvent_t t0 = nullptr, t1 = nullptr;
-      if (h->timing) { HIPCHK(h, hipEventCreate(&t0)); HIPCHK(h, hipEventCreate(&t1)); }
-      HIPCHK(h, launch_propose_scalars(fa.P, st));
-      if (h->timing) HIPCHK(h, hipEventRecord(t0, st));
-      if (want512) HIPCHK(h, launch_chain_fused512(fa, st));
-      else HIPCHK(h, launch_chain_fused(fa, st));
-      if (h->timing) HIPCHK(h, hipEventRecord(t1, st));
+      const int n_seg = (n_steps + seg_max - 1) / seg_max;
+      std::vector<hipEvent_t> tev;
+      if (h->timing) { tev.resize((size_t)2 * n_seg); for (auto& e : tev) HIPCHK(h, hipEventCreate(&e)); }
+      for (int k = 0; k < n_seg; ++k) {
+        const int off = k * seg_max;
+        const int ns = std::min(seg_max, n_steps - off);
+        a.n_steps = ns; a.in_stride = ns; a.rec_offset = off;
+        fa.P = make_propose(h, rf, ns, step0 + off, seeds);
+        fa.P.scalars = h->d_scalars[0];
+        fa.P.size_idx = sc.size_idx; fa.P.centre = sc.centre; fa.P.u = sc.u;
+        HIPCHK(h, launch_propose_scalars(fa.P, st));
+        if (h->timing) HIPCHK(h, hipEventRecord(tev[2 * k], st));
+        HIPCHK(h, launch_chain_fused(fa, st));
+        if (h->timing) HIPCHK(h, hipEventRecord(tev[2 * k + 1], st));
+      }
       rc = check_device_flag(h, st, "gsm_run_philox");
       if (h->timing) {
-        float ms = 0;
         h->t_step_ms = h->t_prop_ms = 0; h->n_step_launch = h->n_prop_launch = 0;
-        if (hipEventElapsedTime(&ms, t0, t1) == hipSuccess) { h->t_step_ms = ms; h->n_step_launch = 1; }
-        hipEventDestroy(t0); hipEventDestroy(t1);
+        for (int k = 0; k < n_seg; ++k) {
+          float ms = 0;
+          if (hipEventElapsedTime(&ms, tev[2 * k], tev[2 * k + 1]) == hipSuccess) { h->t_step_ms += ms; h->n_step_launch++; }
+        }
+        for (auto& e : tev) hipEventDestroy(e);
       }
       return rc;
     }

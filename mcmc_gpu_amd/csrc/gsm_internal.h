@@ -145,10 +145,10 @@ hipError_t launch_pack_static(const StaticFields& S, double2* svx, double2* svy,
 hipError_t launch_residual(const StaticFields& S, int n_chains, const double* beds, double* out, hipStream_t st);
 hipError_t launch_propose(const ProposeArgs& a, hipStream_t st);
 hipError_t launch_propose_scalars(const ProposeArgs& a, hipStream_t st);
+hipError_t launch_spectral_from_noise(const ProposeArgs& a, const int32_t* size_idx, const double* rf_scalars, const double* noise_re,
+                                      const double* noise_im, const double* nugget_field, hipStream_t st);
 hipError_t launch_chain_fused(const FusedArgs& a, hipStream_t st);
 bool fused_supported(const FusedArgs& a);
-hipError_t launch_chain_fused512(const FusedArgs& a, hipStream_t st);
-bool fused512_supported(const FusedArgs& a);
 int propose_max_tiles_per_wave();
 int propose_max_tiles1_per_wave();
 int propose_waves();

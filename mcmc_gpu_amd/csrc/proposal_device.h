@@ -148,10 +148,17 @@ __device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const Pro
 // must issue exactly HOOK_VMEM vector-memory instructions --
 // the fused kernel issues the loads of the chain state there, so that they fly during the two MFMA stages without
 // occupying registers during the register-hungry coefficient phase.
-template <int NT, bool TABLDS, int HOOK_VMEM, class Hook, class OMap>
+//
+// NOISE_IN (gsm_spectral_from_noise, the value pin against the reference): the coefficients are not drawn but formed from
+// caller-supplied white-noise planes N1, N2 of the full (bh, bw) spectrum, X[k] = amp(k) ((N1[k] + N1[-k])/2 +
+// i (N2[k] - N2[-k])/2) -- the Hermitian part of the reference's (N1 + i N2) sqrt(S) (MCMC.py:242-247) -- and the nugget
+// term is the caller's rng.normal(0, sqrt(nug)) plane.  Everything downstream of the coefficients is the same code.
+struct NoiseIn { const double* re; const double* im; const double* nug; };
+
+template <int NT, bool TABLDS, int HOOK_VMEM, bool NOISE_IN = false, class Hook, class OMap>
 __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& a, const PropScalars& sc, const uint64_t seed,
                                               const int64_t step, double* plds, double* red, double* tabA, double* tabG, Hook after_coeff,
-                                              double* __restrict__ out, OMap omap) {
+                                              double* __restrict__ out, OMap omap, const NoiseIn noise = NoiseIn{nullptr, nullptr, nullptr}) {
   constexpr int NW = NT / 64, MAXT = 16 / NW;
   const int SX = a.lds_sx, ST = a.lds_st;
   double* Pr = plds;                       // 4 planes [KRmax][SX]: P re, P im, M re, M im
@@ -210,7 +217,18 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
       const int kx = i - ky * ncol;
       const int kyc = bh - ky;
       const bool paired = (ky != 0) && (ky != hh);
-      double amp, g1, g2, h1 = 0.0, h2 = 0.0;
+      double amp, g1 = 0.0, g2 = 0.0, h1 = 0.0, h2 = 0.0;
+      double ar, ai, br = 0.0, bi = 0.0;   // X[ky], X[bh - ky]
+      if (NOISE_IN) {
+        amp = spectral_amp(P, sc, ky, kx, bh, bw, inv_x, inv_y);
+        const int nky = (ky == 0) ? 0 : kyc, nkx = (kx == 0) ? 0 : bw - kx;      // -k modulo the block shape
+        ar = amp * (0.5 * (noise.re[ky * bw + kx] + noise.re[nky * bw + nkx]));
+        ai = amp * (0.5 * (noise.im[ky * bw + kx] - noise.im[nky * bw + nkx]));
+        if (paired) {                                                            // row bh - ky; its partner row is ky
+          br = amp * (0.5 * (noise.re[kyc * bw + kx] + noise.re[ky * bw + nkx]));
+          bi = amp * (0.5 * (noise.im[kyc * bw + kx] - noise.im[ky * bw + nkx]));
+        }
+      } else {
       if (a.dbg & 1) { amp = 1.0; g1 = ky; g2 = kx; h1 = 1.0; h2 = 2.0; }
       else {
         amp = spectral_amp(P, sc, ky, kx, bh, bw, inv_x, inv_y);
@@ -220,7 +238,6 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
         normals2(seed, step, kStreamSpectrum, (uint32_t)(kyc * ncol + kx), h1, h2);
         if (!paired) { h1 = 0.0; h2 = 0.0; }
       }
-      double ar, ai, br = 0.0, bi = 0.0;   // X[ky], X[bh - ky]
       if (kx > 0 && kx < hw) {
         ar = amp * (g1 * M_SQRT1_2); ai = amp * (g2 * M_SQRT1_2);
         if (paired) { br = amp * (h1 * M_SQRT1_2); bi = amp * (h2 * M_SQRT1_2); }
@@ -229,6 +246,7 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
         br = amp * (0.5 * (h1 + g1)); bi = amp * (0.5 * (h2 - g2));
       } else {
         ar = amp * (0.5 * (g1 + g1)); ai = amp * (0.5 * (g2 - g2));
+      }
       }
       const int o = ky * SX + kx;
       Pr[o] = ar + br; Pi[o] = ai + bi;
@@ -415,7 +433,7 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
   // nothing) the finished value is stored directly; with one, t is stored first and a second pass over cell pairs adds
   // the nugget normals (one Philox block per pair) and applies the mask -- the same operations in the same order.
   const double* __restrict__ mask = a.B.masks + sc.mask_off;
-  const bool with_nugget = (P.nugget_max > 0.0);
+  const bool with_nugget = NOISE_IN ? (noise.nug != nullptr) : (P.nugget_max > 0.0);
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
     const int t = wave + j * NW;
@@ -442,12 +460,16 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
     __syncthreads();
     for (int pr = tid; 2 * pr < ncell; pr += NT) {
       double n1, n2;
-      normals2(seed, step, kStreamNugget, (uint32_t)pr, n1, n2);
       const int o = 2 * pr;
+      if (NOISE_IN) { n1 = noise.nug[o]; n2 = noise.nug[o + 1]; }
+      else {
+        normals2(seed, step, kStreamNugget, (uint32_t)pr, n1, n2);
+        n1 *= sq_nug; n2 *= sq_nug;
+      }
       const int y = o / bw, x = o - y * bw;       // bw is even: the pair (o, o + 1) lies in one row
       const int o0 = omap(y, x), o1 = omap(y, x + 1);
-      if (o0 >= 0) out[o0] = (out[o0] + n1 * sq_nug) * mask[o];
-      if (o1 >= 0) out[o1] = (out[o1] + n2 * sq_nug) * mask[o + 1];
+      if (o0 >= 0) out[o0] = (out[o0] + n1) * mask[o];
+      if (o1 >= 0) out[o1] = (out[o1] + n2) * mask[o + 1];
     }
   }
 }

@@ -33,6 +33,31 @@
 
 namespace gsm {
 
+// spectral-amplitude parameters of a proposal from its range draws (MCMC.py:209-239)
+__device__ __forceinline__ void spectral_params(PropScalars& r, const gsm_rf_params& P) {
+  double lx, ly;
+  if (P.model == GSM_MODEL_GAUSSIAN) { lx = r.range_x / sqrt(3.0); ly = r.range_y / sqrt(3.0); }
+  else if (P.model == GSM_MODEL_EXPONENTIAL) { lx = r.range_x / 3.0; ly = r.range_y / 3.0; }
+  else { lx = r.range_x / 2.0; ly = r.range_y / 2.0; }
+  r.aa = sqrt(lx * ly);
+  r.m_const = 0.0; r.m_kappa = 0.0;
+  if (P.model == GSM_MODEL_MATERN) {
+    const double nu = (P.smoothness != 0.0) ? P.smoothness : 1.0;
+    r.m_const = (4.0 * M_PI * tgamma(nu + 1.0) * pow(2.0 * nu, nu)) / (tgamma(nu) * pow(r.aa, 2.0 * nu));
+    r.m_kappa = 2.0 * nu / (r.aa * r.aa);
+  }
+}
+
+// block shape, DFT-table offsets and mask offset of size index r.si
+__device__ __forceinline__ void block_shape(PropScalars& r, const ProposeArgs& a) {
+  r.pad = 0;
+  r.bh = a.B.bh[r.si];
+  r.bw = a.B.bw[r.si];
+  r.fy_off = a.fy_off[r.bh];
+  r.g_off = a.g_off[r.bw];
+  r.mask_off = a.B.mask_off[r.si];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // per-proposal scalars: one thread per (chain, step).  Draw layout (stream kStreamScalars):
 //   idx 0: {scale u, nugget u}   idx 1: {range_x u, range_y u}   idx 2: {accept u, centre word}   idx 3: {size word}
@@ -59,24 +84,8 @@ __global__ __launch_bounds__(256) void propose_scalars_kernel(const ProposeArgs 
   const int cell = a.centres[(int)__umul64hi(cw, (uint64_t)a.n_centres)];
   r.row = cell / a.W;
   r.col = cell - r.row * a.W;
-  // spectral amplitude parameters (MCMC.py:209-239)
-  double lx, ly;
-  if (P.model == GSM_MODEL_GAUSSIAN) { lx = r.range_x / sqrt(3.0); ly = r.range_y / sqrt(3.0); }
-  else if (P.model == GSM_MODEL_EXPONENTIAL) { lx = r.range_x / 3.0; ly = r.range_y / 3.0; }
-  else { lx = r.range_x / 2.0; ly = r.range_y / 2.0; }
-  r.aa = sqrt(lx * ly);
-  r.m_const = 0.0; r.m_kappa = 0.0;
-  if (P.model == GSM_MODEL_MATERN) {
-    const double nu = (P.smoothness != 0.0) ? P.smoothness : 1.0;
-    r.m_const = (4.0 * M_PI * tgamma(nu + 1.0) * pow(2.0 * nu, nu)) / (tgamma(nu) * pow(r.aa, 2.0 * nu));
-    r.m_kappa = 2.0 * nu / (r.aa * r.aa);
-  }
-  r.pad = 0;
-  r.bh = a.B.bh[r.si];
-  r.bw = a.B.bw[r.si];
-  r.fy_off = a.fy_off[r.bh];
-  r.g_off = a.g_off[r.bw];
-  r.mask_off = a.B.mask_off[r.si];
+  spectral_params(r, P);
+  block_shape(r, a);
   a.scalars[rec] = r;
   a.size_idx[rec] = r.si;
   a.centre[2 * rec] = r.row;
@@ -102,6 +111,51 @@ __global__ __launch_bounds__(NT, NT / 256) void propose_kernel(const ProposeArgs
   double* __restrict__ out = a.fields + rec * a.field_stride;
   propose_field<NT, false, 0>((int)threadIdx.x, a, sc, a.seeds[chain], a.step0 + s, plds, red, nullptr, nullptr, [] {}, out,
                               [bw = sc.bw](int y, int x) { return y * bw + x; });
+}
+
+// gsm_spectral_from_noise: scalar records from caller-supplied (size index, scale, nugget, ranges) ...
+__global__ __launch_bounds__(256) void noise_scalars_kernel(const ProposeArgs a, const int32_t* __restrict__ size_idx,
+                                                            const double* __restrict__ rf_scalars) {
+  const int rec = blockIdx.x * 256 + threadIdx.x;
+  if (rec >= a.n_steps) return;
+  PropScalars r;
+  r.si = size_idx[rec];
+  if (r.si < 0 || r.si >= a.B.n_sizes) { r.si = 0; r.bh = 0; }   // flagged by the host wrapper before the launch
+  r.scale = rf_scalars[4 * rec]; r.nug = rf_scalars[4 * rec + 1];
+  r.range_x = rf_scalars[4 * rec + 2]; r.range_y = rf_scalars[4 * rec + 3];
+  r.u = 0.0; r.row = 0; r.col = 0;
+  spectral_params(r, a.rf);
+  block_shape(r, a);
+  a.scalars[rec] = r;
+}
+
+// ... and the synthesis itself: propose_field with the coefficients formed from the caller's noise planes
+__global__ __launch_bounds__(512, 2) void spectral_from_noise_kernel(const ProposeArgs a, const double* __restrict__ noise_re,
+                                                                     const double* __restrict__ noise_im,
+                                                                     const double* __restrict__ nugget_field) {
+  extern __shared__ double plds[];
+  double* red = plds + a.lds_main;
+  const int64_t rec = blockIdx.x;
+  const PropScalars sc = a.scalars[rec];
+  const NoiseIn nz{noise_re + rec * a.field_stride, noise_im + rec * a.field_stride,
+                   nugget_field ? nugget_field + rec * a.field_stride : nullptr};
+  propose_field<512, false, 0, true>((int)threadIdx.x, a, sc, 0, 0, plds, red, nullptr, nullptr, [] {},
+                                     a.fields + rec * a.field_stride, [bw = sc.bw](int y, int x) { return y * bw + x; }, nz);
+}
+
+hipError_t launch_spectral_from_noise(const ProposeArgs& a, const int32_t* size_idx, const double* rf_scalars,
+                                      const double* noise_re, const double* noise_im, const double* nugget_field, hipStream_t st) {
+  const size_t lds = ((size_t)a.lds_main + 32) * sizeof(double);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)spectral_from_noise_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(noise_scalars_kernel, dim3((unsigned)((a.n_steps + 255) / 256)), dim3(256), 0, st, a, size_idx, rf_scalars);
+  hipLaunchKernelGGL(spectral_from_noise_kernel, dim3(a.n_steps), dim3(512), lds, st, a, noise_re, noise_im, nugget_field);
+  return hipGetLastError();
 }
 
 hipError_t launch_propose(const ProposeArgs& a_in, hipStream_t st) {

@@ -251,6 +251,40 @@ class GsmEngine:
                     u=u.view(self.n_chains, n_steps), fields=fl,
                     rf_scalars=None if sc is None else sc.view(self.n_chains, n_steps, 4))
 
+    def spectral_from_noise(self, size_idx, rf_scalars, rf, noise_re, noise_im, nugget_fields=None):
+        """The device spectral synthesis on caller-supplied white noise (gsm_spectral_from_noise): for field r,
+        size_idx[r] picks the block shape, rf_scalars[r] = (scale, nugget, range_x, range_y) as drawn at
+        MCMC.py:200-207 (scale already / 3), noise_re[r] / noise_im[r] are the two (bh, bw) normal planes of MCMC.py:242,
+        nugget_fields[r] the rng.normal(0, sqrt(nug)) plane of MCMC.py:251 (or None).  Returns the masked fields, a list
+        of (bh, bw) arrays."""
+        size_idx = np.ascontiguousarray(size_idx, dtype=np.int32)
+        n = size_idx.shape[0]
+        sc = np.ascontiguousarray(rf_scalars, dtype=np.float64)
+        if sc.shape != (n, 4):
+            raise ValueError("rf_scalars must have shape (n, 4)")
+
+        def pack(planes):
+            out = np.zeros((n, self.field_stride))
+            for r, a in enumerate(planes):
+                a = np.asarray(a, dtype=np.float64)
+                if a.shape != (int(self.bh[size_idx[r]]), int(self.bw[size_idx[r]])):
+                    raise ValueError("noise plane shape does not match its block size")
+                out[r, :a.size] = a.ravel()
+            return self._f64(out)
+
+        d_re, d_im = pack(noise_re), pack(noise_im)
+        d_ng = pack(nugget_fields) if nugget_fields is not None else None
+        d_si, d_sc = torch.as_tensor(size_idx).to(self.dev), self._f64(sc)
+        out = torch.zeros((n, self.field_stride), dtype=torch.float64, device=self.dev)
+        p = rf if isinstance(rf, RfParams) else self.rf_struct(rf)
+        with torch.cuda.device(self.dev):
+            self._check(self.lib.gsm_spectral_from_noise(self.h, n, _ptr(d_si), _ptr(d_sc), C.byref(p), _ptr(d_re), _ptr(d_im),
+                                                         _ptr(d_ng), _ptr(out), self.field_stride, self._stream()))
+            torch.cuda.synchronize(self.dev)
+        h = out.cpu().numpy()
+        return [h[r, :int(self.bh[size_idx[r]] * self.bw[size_idx[r]])].reshape(int(self.bh[size_idx[r]]), int(self.bw[size_idx[r]]))
+                for r in range(n)]
+
     def enable_timing(self, on=True):
         self._check(self.lib.gsm_enable_timing(self.h, 1 if on else 0))
 
@@ -262,7 +296,7 @@ class GsmEngine:
 
     def set_fused(self, on: bool):
         """Philox mode, spectral generator: fused chain kernel (default) or the two-kernel pipeline (same results)."""
-        self._check(self.lib.gsm_set_fused(self.h, int(on)))   # 0 two kernels, 1 fused (1024 threads), 2 fused (512 threads x 2 per CU)
+        self._check(self.lib.gsm_set_fused(self.h, int(bool(on))))
 
     def last_run_fused(self) -> int:
         return int(self.lib.gsm_last_run_fused(self.h))

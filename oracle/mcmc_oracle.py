@@ -168,8 +168,9 @@ def spectral_amplitude(shape, res, model_name, range_x, range_y, smoothness=None
     return np.sqrt(S)
 
 
-def spectral_field(rng: np.random.Generator, p: RFParams, shape, res, trace: dict | None = None):
-    """One spectral-synthesis realisation; draw order of MCMC.py:200-251 (SURVEY a13)."""
+def spectral_draws(rng: np.random.Generator, p: RFParams, shape) -> dict:
+    """The random numbers of one spectral_synthesis_field call, consumed in the reference's order (MCMC.py:200-207, :242,
+    :251): scale, nugget, range(s), two normal planes, the nugget plane."""
     ny, nx = shape
     scale = rng.uniform(p.scale_min, p.scale_max) / 3.0
     nug = rng.uniform(0.0, p.nugget_max)
@@ -178,13 +179,27 @@ def spectral_field(rng: np.random.Generator, p: RFParams, shape, res, trace: dic
         range_y = rng.uniform(p.range_min_y, p.range_max_y)
     else:
         range_x = range_y = rng.uniform(p.range_min_x, p.range_max_x)
-    amp = spectral_amplitude(shape, res, p.model_name, range_x, range_y, p.smoothness)
-    noise = rng.normal(size=(ny, nx)) + 1j * rng.normal(size=(ny, nx))
+    n_re = rng.normal(size=(ny, nx))
+    n_im = rng.normal(size=(ny, nx))
+    n_nug = rng.normal(0, np.sqrt(nug), size=(ny, nx))
+    return dict(scale=scale, nug=nug, range_x=range_x, range_y=range_y, n_re=n_re, n_im=n_im, n_nug=n_nug)
+
+
+def spectral_from_draws(d: dict, p: RFParams, shape, res) -> np.ndarray:
+    """The arithmetic of MCMC.py:209-251 on given draws."""
+    amp = spectral_amplitude(shape, res, p.model_name, d["range_x"], d["range_y"], p.smoothness)
+    noise = d["n_re"] + 1j * d["n_im"]
     fld = np.fft.ifft2(noise * amp).real
     fld = (fld - np.mean(fld)) / (np.std(fld) + 1e-12)
-    fld = fld * scale + rng.normal(0, np.sqrt(nug), size=(ny, nx))
+    return fld * d["scale"] + d["n_nug"]
+
+
+def spectral_field(rng: np.random.Generator, p: RFParams, shape, res, trace: dict | None = None):
+    """One spectral-synthesis realisation; draw order of MCMC.py:200-251 (SURVEY a13)."""
+    d = spectral_draws(rng, p, shape)
+    fld = spectral_from_draws(d, p, shape, res)
     if trace is not None:
-        trace.update(scale=scale, nug=nug, range_x=range_x, range_y=range_y)
+        trace.update(scale=d["scale"], nug=d["nug"], range_x=d["range_x"], range_y=d["range_y"])
     return fld
 
 

@@ -36,3 +36,42 @@ def replay_inputs(eng, outs):
     u = np.array([o[7].u for o in outs])
     fields = eng.pack_fields([o[7].fields for o in outs])
     return size_idx, centre, u, fields
+
+
+def windows_count(blocks, acc, H, W):
+    cnt = np.zeros((H, W), dtype=np.int64)
+    for (row, col, bh, bw), a in zip(blocks, acc):
+        if a:
+            r0, r1 = max(0, row - bh // 2), min(H, row + bh // 2)
+            c0, c1 = max(0, col - bw // 2), min(W, col + bw // 2)
+            cnt[r0:r1, c0:c1] += 1
+    return cnt
+
+
+def check_chain_invariants(eng, region_mask, beds0, loss0, loss, acc, blk, sample_chains):
+    """Size-independent properties of a finished Philox-mode run (no oracle needed), see test_gpu_fullsize.py:
+    P1 carried energy == from-scratch recompute of the final beds, bit for bit, every chain;
+    P2 compensated carried sum == sum(energy) (1e-12), last loss == recomputed loss (1e-10);
+    P3 resampled == accepted windows covering each cell inside the update mask (sample of chains);
+    P4 rejected steps repeat the previous loss exactly, cells outside the update mask never change.
+    beds0: device tensor of the initial beds (state dtype).  Leaves the engine state recomputed from its final beds."""
+    import torch
+    H, W = eng.H, eng.W
+    beds = eng.beds.clone(); energy = eng.energy.clone(); res = eng.resampled.clone(); lsum = eng.loss_sum.clone()
+    loss_re = eng.set_state(beds, resampled=res)
+    assert torch.equal(eng.energy, energy), "carried energy differs from a full recompute"
+    s_carried = (lsum[:, 0] + lsum[:, 1]).cpu().numpy()
+    s_energy = energy.sum(dim=(1, 2), dtype=torch.float64).cpu().numpy()
+    np.testing.assert_allclose(s_carried, s_energy, rtol=1e-12)
+    np.testing.assert_allclose(loss[:, -1], loss_re, rtol=1e-10)
+    prev = np.concatenate([loss0[:, None], loss[:, :-1]], axis=1)
+    assert np.array_equal(loss[acc == 0], prev[acc == 0])
+    assert (loss[acc == 1] != prev[acc == 1]).mean() > 0.99
+    outside = torch.as_tensor(np.asarray(region_mask) == 0, device=beds.device)
+    assert torch.equal(beds[:, outside], beds0[:, outside])
+    assert not torch.equal(beds, beds0)
+    resh = res[list(sample_chains)].cpu().numpy()
+    for k, c in enumerate(sample_chains):
+        exp = windows_count(blk[c], acc[c], H, W) * (np.asarray(region_mask) == 1)
+        assert np.array_equal(resh[k], exp)
+    return beds, res

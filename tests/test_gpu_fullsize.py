@@ -7,7 +7,8 @@ properties -- the oracle cannot run this many chain-steps, the invariants below 
       equals the recomputed loss (<= 1e-10 rel, north_star's bound)
   P3  resampled counts == number of accepted proposals covering each cell inside the update mask, exactly
   P4  rejected steps repeat the previous loss exactly; cells outside the update mask never change
-  P5  the same launch split differently (batch 8 vs 32) gives identical results
+  P5  the fused chain kernel and the two-kernel pipeline (another batch size) give identical results on a 64-chain slice,
+      and each path is asserted to have run (gsm_last_run_fused)
 and non-square / edge-clipping geometry on a smaller ragged grid."""
 import numpy as np
 import pytest
@@ -19,50 +20,32 @@ from mcmc_gpu_amd import synthetic
 pytestmark = pytest.mark.gpu
 
 
-def _windows_count(blocks, acc, H, W):
-    cnt = np.zeros((H, W), dtype=np.int64)
-    for (row, col, bh, bw), a in zip(blocks, acc):
-        if a:
-            r0, r1 = max(0, row - bh // 2), min(H, row + bh // 2)
-            c0, c1 = max(0, col - bw // 2), min(W, col + bw // 2)
-            cnt[r0:r1, c0:c1] += 1
-    return cnt
-
-
 def test_full_size_invariants():
+    from gpu_common import check_chain_invariants
     H, n_chains, n_steps = 256, 1024, 96
     prob, ch, rf = synthetic.template(H)
     eng = ch._make_engine(rf, n_chains, 0)
     beds0 = synthetic.initial_beds(prob, n_chains)
     loss0 = eng.set_state(beds0)
+    d_beds0 = eng.beds.clone()
     seeds = list(range(500, 500 + n_chains))
     loss, acc, blk = eng.run_philox(n_steps, 0, seeds, rf, batch=32)
-    beds = eng.beds.clone(); energy = eng.energy.clone(); res = eng.resampled.clone(); lsum = eng.loss_sum.clone()
+    assert eng.last_run_fused() == 1
     assert 0.45 < acc.mean() < 0.65
-    # P1 / P2: recompute everything from the final beds
-    loss_re = eng.set_state(beds)
-    assert torch.equal(eng.energy, energy), "carried energy differs from a full recompute"
-    s_carried = (lsum[:, 0] + lsum[:, 1]).cpu().numpy()
-    s_energy = energy.sum(dim=(1, 2), dtype=torch.float64).cpu().numpy()
-    np.testing.assert_allclose(s_carried, s_energy, rtol=1e-12)
-    np.testing.assert_allclose(loss[:, -1], loss_re, rtol=1e-10)
-    # P4: rejected steps carry the loss; outside the region nothing moves
-    prev = np.concatenate([loss0[:, None], loss[:, :-1]], axis=1)
-    assert np.array_equal(loss[acc == 0], prev[acc == 0])
-    assert (loss[acc == 1] != prev[acc == 1]).mean() > 0.99
-    outside = torch.as_tensor(prob["region_mask"] == 0, device=beds.device)
-    assert torch.equal(beds[:, outside], torch.as_tensor(beds0, device=beds.device)[:, outside])
-    assert not torch.equal(beds, torch.as_tensor(beds0, device=beds.device))
-    # P3 on a sample of chains (host loop)
-    resh = res.cpu().numpy()
-    for c in (0, 1, 511, 1023):
-        exp = _windows_count(blk[c], acc[c], H, H) * (prob["region_mask"] == 1)
-        assert np.array_equal(resh[c], exp)
-    # P5
-    eng.set_state(beds0)
-    loss8, acc8, blk8 = eng.run_philox(n_steps, 0, seeds, rf, batch=8)
-    assert np.array_equal(acc8, acc) and np.array_equal(loss8, loss) and np.array_equal(blk8, blk)
-    assert torch.equal(eng.beds, beds) and torch.equal(eng.resampled, res)
+    check_chain_invariants(eng, prob["region_mask"], d_beds0, loss0, loss, acc, blk, (0, 1, 511, 1023))
+    eng.close()
+    # P5: the two launch structures (fused chain kernel / two-kernel pipeline with another batch size) on a 64-chain slice
+    eng = ch._make_engine(rf, 64, 0)
+    res = []
+    for fused, batch in ((1, 32), (0, 8)):
+        eng.set_fused(fused)
+        eng.set_state(beds0[:64])
+        out = eng.run_philox(n_steps, 0, seeds[:64], rf, batch=batch)
+        assert eng.last_run_fused() == fused
+        res.append(out + (eng.beds.cpu().numpy().copy(), eng.resampled.cpu().numpy().copy(), eng.energy.cpu().numpy().copy()))
+    for x, y in zip(*res):
+        assert np.array_equal(x, y)
+    assert np.array_equal(res[0][0], loss[:64]) and np.array_equal(res[0][1], acc[:64]) and np.array_equal(res[0][2], blk[:64])
     eng.close()
 
 

@@ -105,30 +105,6 @@ def test_fused_segments_reproduce_unsplit_run():
     eng.close()
 
 
-def test_fused_512_thread_form_equals_1024_thread_form():
-    """gsm_set_fused(h, 2): two 512-thread workgroups per CU (bed tile updated in place, stencil operands from L2).
-    Different data placement, same arithmetic and summation order: bit-identical to the 1024-thread kernel."""
-    rfp = orc.standard_rf_params()
-    for H, n_chains, n in ((64, 4, 45), (256, 2, 24)):
-        eng, prob, cfg, pairs, masks, _ = make_engine(H, n_chains)
-        rfp.resolution = prob["resolution"]
-        if H == 256:
-            eng.set_centres(np.ones_like(cfg.region_mask))     # clipped windows too
-        seeds = [61 + c for c in range(n_chains)]
-        beds0 = np.stack([orc.chain_initial_bed(prob, c) for c in range(n_chains)])
-        res = []
-        for mode in (1, 2):
-            eng.set_fused(mode)
-            eng.set_state(beds0)
-            loss, acc, blk = eng.run_philox(n, 9, seeds, rfp)
-            assert eng.last_run_fused() == mode
-            res.append((loss, acc, blk, eng.beds.cpu().numpy().copy(), eng.resampled.cpu().numpy().copy(),
-                        eng.energy.cpu().numpy().copy(), eng.loss_sum.cpu().numpy().copy()))
-        for x, y in zip(*res):
-            assert np.array_equal(x, y)
-        eng.close()
-
-
 def test_fused_nan_fields_and_thickness_guard_equal_two_kernel_pipeline():
     """NaN holes in the bed, a NaN velocity patch, a NaN dhdt cell (nansum semantics, MCMC.py:1041, :1328) and a surface
     lowered so far in one corner that proposals there trip the thickness guard (loss = inf, MCMC.py:1321-1329): the fused
@@ -153,8 +129,60 @@ def test_fused_nan_fields_and_thickness_guard_equal_two_kernel_pipeline():
         assert np.array_equal(x, y, equal_nan=True)
     loss, acc, blk = a[0], a[1], a[2]
     assert np.isfinite(loss).all()
-    # proposals centred in the thin-ice corner are (almost) always rejected by the guard, the others are not
-    in_corner = (blk[..., 0] >= 12) & (blk[..., 0] < 26) & (blk[..., 1] >= 12) & (blk[..., 1] < 26)
-    assert in_corner.sum() > 5
-    assert acc[in_corner].mean() < 0.5 * acc[~in_corner].mean()
+    # The guard, deterministically: regenerate the very fields the fused kernel drew (gsm_propose_philox, same counters),
+    # walk every chain on the host with the device's accept flags, and require that EVERY proposal whose candidate bed
+    # leaves a cell of its window with surf - bed_next <= 0 (inside the update mask, MCMC.py:1321-1329) was rejected.
+    eng.set_state(beds0)
+    p = eng.propose_philox(80, 0, seeds, rfp)
+    fields = p["fields"].cpu().numpy()
+    w = cfg.crf_data_weight
+    upd = cfg.region_mask == 1
+    tripped = accepted_in_corner = 0
+    for c in range(6):
+        bed = beds0[c].copy()
+        for s in range(80):
+            row, col, bh, bw = (int(v) for v in blk[c, s])
+            r0, r1 = max(0, row - bh // 2), min(64, row + bh // 2)
+            c0, c1 = max(0, col - bw // 2), min(64, col + bw // 2)
+            mr0, mc0 = max(bh - r1, 0), max(bw - c1, 0)
+            f = fields[c, s, : bh * bw].reshape(bh, bw)[mr0:mr0 + r1 - r0, mc0:mc0 + c1 - c0]
+            nxt = bed.copy()
+            win = nxt[r0:r1, c0:c1]
+            m = upd[r0:r1, c0:c1]
+            win[m] = (win + f * w[r0:r1, c0:c1])[m]
+            bad = ((cfg.surf[r0:r1, c0:c1] - win) <= 0) & m
+            if bad.any():
+                tripped += 1
+                assert acc[c, s] == 0, f"chain {c} step {s}: thickness guard tripped but the proposal was accepted"
+            if acc[c, s]:
+                bed = nxt
+                accepted_in_corner += int(12 <= row < 26 and 12 <= col < 26)
+        assert np.array_equal(bed, a[3][c], equal_nan=True), "host walk of the accepted proposals does not reproduce the device bed"
+    assert tripped >= 20, f"only {tripped} proposals tripped the guard: the test does not exercise it"
+    eng.close()
+
+
+def test_fused_internal_segments_are_invisible(monkeypatch):
+    """gsm_run_philox cuts a long call into launches of at most 4096 steps (scratch sized by the segment, ADVICE r1);
+    GSM_FUSED_SEGMENT lowers the cap: 7-step segments (a ragged last one) must reproduce the single-launch run exactly."""
+    rfp = orc.standard_rf_params()
+    eng, prob, cfg, pairs, masks, _ = make_engine(64, 3)
+    rfp.resolution = prob["resolution"]
+    seeds = [81, 82, 83]
+    beds0 = np.stack([orc.chain_initial_bed(prob, c) for c in range(3)])
+    res = []
+    for cap in (None, "7"):
+        if cap:
+            monkeypatch.setenv("GSM_FUSED_SEGMENT", cap)
+        eng.set_state(beds0)
+        loss, acc, blk = eng.run_philox(45, 2 ** 33 + 5, seeds, rfp)
+        assert eng.last_run_fused() == 1
+        res.append((loss, acc, blk, eng.beds.cpu().numpy().copy(), eng.resampled.cpu().numpy().copy(), eng.loss_sum.cpu().numpy().copy()))
+    monkeypatch.delenv("GSM_FUSED_SEGMENT")
+    for x, y in zip(*res):
+        assert np.array_equal(x, y)
+    eng.enable_timing(True)
+    monkeypatch.setenv("GSM_FUSED_SEGMENT", "10")
+    eng.run_philox(45, 0, seeds, rfp)
+    assert eng.last_timing()["step_launches"] == 5
     eng.close()
