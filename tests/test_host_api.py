@@ -22,7 +22,9 @@ def test_library_loads_and_exports_every_declared_symbol():
             "gsm_version", "gsm_enable_timing", "gsm_last_timing", "gsm_philox_selftest"} <= set(names)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.gsm_version().decode().endswith("gfx950")
+    v = lib.gsm_version().decode()
+    assert " gfx950 src:" in v and v.endswith(_lib.source_hash())      # the binary is the one built from these sources
+    assert "gsm_spectral_from_noise" in names
     # the shared object carries a gfx950 code object
     out = subprocess.run(["strings", "-n", "6", str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
     assert "gfx950" in out
