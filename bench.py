@@ -195,6 +195,7 @@ def measure(args, H, n_local, generator, state, inner, batch, steps, warmup, ran
     blk = torch.empty((n_local, inner, 4), dtype=torch.int32, device=dev)
     acc_all = torch.empty((n_local, n_timed), dtype=torch.uint8, device=dev)
     loss_all = torch.empty((n_local, n_timed), dtype=torch.float64, device=dev)
+    blk_all = torch.empty((n_local, n_timed, 4), dtype=torch.int32, device=dev) if rank == 0 else None
 
     def segment_end():
         """Per-chain caches to every rank, posterior-mean field, small results to the host."""
@@ -218,18 +219,14 @@ def measure(args, H, n_local, generator, state, inner, batch, steps, warmup, ran
     torch.cuda.synchronize(dev)
     t_step = t_prop = 0.0
     n_step_l = n_prop_l = 0
-    bytes_total = 0
-    flops_total = 0.0
     t0 = time.perf_counter()
     for k in range(steps):
         eng.run_philox(inner, step0, seeds, p, batch=batch, out=(loss, acc, blk), to_host=False)
         step0 += inner
         sl = slice(k * inner, (k + 1) * inner)
         acc_all[:, sl] = acc; loss_all[:, sl] = loss
-        if rank == 0:    # bookkeeping of the roofline numerator (device-side reduction of this step's records)
-            bytes_total += algorithmic_bytes(blk, acc, H, H, sbytes)
-            if generator == "cholesky":
-                flops_total += float(((blk[..., 2].double() * blk[..., 3].double()) ** 2).sum().item())
+        if rank == 0:
+            blk_all[:, sl] = blk     # the roofline numerator is summed from these records after the timed region
         tm = eng.last_timing()
         t_step += tm["step_ms"] * tm["step_launches"]; n_step_l += tm["step_launches"]
         t_prop += tm["proposal_ms"] * tm["proposal_launches"]; n_prop_l += tm["proposal_launches"]
@@ -240,10 +237,18 @@ def measure(args, H, n_local, generator, state, inner, batch, steps, warmup, ran
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     fused = bool(eng.last_run_fused())
     eng.close()
+    del eng
     if rank != 0:
         return None
 
     chain_steps = n_total * n_timed
+    bytes_total, flops_total = 0, 0.0
+    for k in range(steps):       # device-side sums, one bench step at a time (bounded temporaries)
+        sl = slice(k * inner, (k + 1) * inner)
+        bytes_total += algorithmic_bytes(blk_all[:, sl], acc_all[:, sl], H, H, sbytes)
+        if generator == "cholesky":
+            flops_total += float(((blk_all[:, sl, 2].double() * blk_all[:, sl, 3].double()) ** 2).sum().item())
+    del blk_all
     bytes_per_launch = bytes_total / max(n_step_l, 1)
     step_ms = t_step / max(n_step_l, 1); prop_ms = t_prop / max(n_prop_l, 1)
     steps_per_launch = n_timed / max(n_step_l, 1)

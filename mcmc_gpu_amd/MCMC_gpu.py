@@ -30,7 +30,7 @@ import numpy as np
 from . import Topography  # noqa: F401  (re-exported like the reference namespace does)
 
 __all__ = ["RandField", "chain_crf_gpu", "init_lsc_chain_by_instance", "initiate_RF_by_instance",
-           "spectral_synthesis_field", "run_many", "min_dist_from_mask"]
+           "spectral_synthesis_field", "run_many", "run_many_replay", "draw_chunk", "min_dist_from_mask"]
 
 
 def min_dist_from_mask(xx, yy, mask, device=None):
@@ -184,6 +184,71 @@ class RandField:
         return f * self.edge_masks[idx]
 
 
+def draw_chunk(RF, rng, n, H, W, update_in_region, region_mask):
+    """n Metropolis steps' worth of host draws in the reference's per-generator order: RF.rng gives the proposal block
+    (MCMC.py:742-778 -> :176-254), `rng` (the chain's generator) the block centre -- rejection on region_mask when
+    update_in_region (MCMC.py:1253-1261) -- and the accept uniform (MCMC.py:1336), which the reference always draws.
+    None of this depends on the chain's state, so draws can be made ahead of the device (and in other processes)."""
+    size_idx = np.empty(n, dtype=np.int32)
+    centre = np.empty((n, 2), dtype=np.int32)
+    u = np.empty(n)
+    fields = []
+    for s in range(n):
+        f = RF.get_rfblock()
+        fields.append(f)
+        size_idx[s] = RF._last_size_idx
+        if update_in_region:
+            while True:
+                ix = rng.integers(low=0, high=H, size=1)[0]
+                iy = rng.integers(low=0, high=W, size=1)[0]
+                if region_mask[ix, iy] == 1:
+                    break
+        else:
+            ix = rng.integers(low=0, high=H, size=1)[0]
+            iy = rng.integers(low=0, high=W, size=1)[0]
+        centre[s] = (ix, iy)
+        u[s] = rng.random()
+    return size_idx, centre, u, fields
+
+
+# ---- host process pool that draws replay-mode proposals ahead of the device (run_many_replay) -------------------------
+_POOL = {}
+
+
+def _pool_init(rf_param, H, W, update_in_region, region_mask, shm_names, shm_shape):
+    """Pool initializer: rebuild the RandField template once per worker, attach the shared field buffers."""
+    from multiprocessing import shared_memory
+    rf_param = dict(rf_param)
+    rf_param['rng_seed'] = 0
+    _POOL['rf'] = initiate_RF_by_instance(rf_param)
+    _POOL['geom'] = (H, W, update_in_region, region_mask)
+    _POOL['shm'] = [shared_memory.SharedMemory(name=nm) for nm in shm_names]
+    try:    # the parent owns (and unlinks) the segments: keep this process's resource tracker out of it (bpo-39959)
+        from multiprocessing import resource_tracker
+        for m in _POOL['shm']:
+            resource_tracker.unregister(m._name, 'shared_memory')
+    except Exception:
+        pass
+    _POOL['buf'] = [np.ndarray(shm_shape, dtype=np.float64, buffer=m.buf) for m in _POOL['shm']]
+
+
+def _pool_draw(task):
+    """One chain's draws for one chunk: (chain slot, buffer index, n, RandField generator state, chain generator state)
+    -> (slot, size_idx, centre, u, new states); the masked fields go straight into the shared buffer
+    [n_chains, chunk, field_stride]."""
+    slot, which, n, rf_state, chain_state = task
+    rf = _POOL['rf']
+    rf.rng.bit_generator.state = rf_state
+    rng = np.random.default_rng(0)
+    rng.bit_generator.state = chain_state
+    H, W, upd, region = _POOL['geom']
+    si, ce, u, fields = draw_chunk(rf, rng, n, H, W, upd, region)
+    out = _POOL['buf'][which][slot]
+    for s, f in enumerate(fields):
+        out[s, :f.size] = f.ravel()
+    return slot, si, ce, u, rf.rng.bit_generator.state, rng.bit_generator.state
+
+
 class chain_crf_gpu:
     """Large-scale random-field Metropolis chain executed on the MI355X (reference: chain / chain_crf /
     chain_crf_gpu, MCMC.py:780-1443, MCMC_gpu.py:149-582).  All state lives in plain attributes so the
@@ -282,27 +347,7 @@ class chain_crf_gpu:
     def _draw_chunk(self, RF, n):
         """n steps of host draws in the reference's per-generator order."""
         H, W = self.xx.shape
-        size_idx = np.empty(n, dtype=np.int32)
-        centre = np.empty((n, 2), dtype=np.int32)
-        u = np.empty(n)
-        fields = []
-        rng = self.rng
-        for s in range(n):
-            f = RF.get_rfblock()
-            fields.append(f)
-            size_idx[s] = RF._last_size_idx
-            if self.update_in_region:
-                while True:
-                    ix = rng.integers(low=0, high=H, size=1)[0]
-                    iy = rng.integers(low=0, high=W, size=1)[0]
-                    if self.region_mask[ix, iy] == 1:
-                        break
-            else:
-                ix = rng.integers(low=0, high=H, size=1)[0]
-                iy = rng.integers(low=0, high=W, size=1)[0]
-            centre[s] = (ix, iy)
-            u[s] = rng.random()
-        return size_idx, centre, u, fields
+        return draw_chunk(RF, self.rng, n, H, W, self.update_in_region, self.region_mask)
 
     def _sample_indices(self):
         loc = np.asarray(self.sample_loc)
@@ -421,6 +466,104 @@ def run_many(chain, RF, initial_beds, seeds, n_iter, batch=8, device=None, step0
         bc = np.vstack([np.full((1, 4), np.nan), blk[c].astype(np.float64)])
         out.append((beds_out[c], lc.copy(), np.zeros(int(n_iter)), lc, sc, res[c], bc))
     return out
+
+
+def run_many_replay(chain, RF, initial_beds, rf_states, chain_states, n_iter, chunk=None, n_workers=None, device=None,
+                    progress=False):
+    """Replay mode for MANY chains of one template in ONE handle: what the reference's pool computes with one chain per
+    process (largeScaleChain_multiprocessing_GPU.py:84-85).  Chain c draws from its own two NumPy generators
+    (rf_states[c], chain_states[c]: `Generator.bit_generator.state` dicts) exactly as chain_crf.run does; the draws for
+    chunk k+1 are made by a pool of host processes (they do not depend on the chains' state) while the device steps
+    chunk k; the fields travel through shared memory.  Returns (list of chain.run(..., only_save_last_bed=True) tuples,
+    final rf states, final chain states) -- results equal n independent chain_crf_gpu.run calls."""
+    import multiprocessing as mp
+    import os
+    from multiprocessing import shared_memory
+    import torch
+    if not isinstance(RF, RandField):
+        raise TypeError('The arugment "RF" has to be an object of the class RandField')
+    if not getattr(RF, 'spectral', False):
+        raise NotImplementedError('only the spectral-synthesis generator (set_generation_method(True)) is built')
+    beds = np.asarray(initial_beds, dtype=np.float64)
+    n_chains = beds.shape[0]
+    if len(rf_states) != n_chains or len(chain_states) != n_chains:
+        raise ValueError('need one RandField and one chain generator state per chain')
+    H, W = chain.xx.shape
+    n_iter = int(n_iter)
+    n_steps = n_iter - 1
+    eng = chain._make_engine(RF, n_chains, device)
+    shms = []
+    pool = None
+    try:
+        loss0 = eng.set_state(beds)
+        loss = np.zeros((n_chains, n_steps)); acc = np.zeros((n_chains, n_steps), np.uint8)
+        blocks = np.zeros((n_chains, n_steps, 4))
+        rf_states, chain_states = list(rf_states), list(chain_states)
+        if n_steps > 0:
+            stride = eng.field_stride
+            if chunk is None:   # two shared buffers of at most ~256 MiB each
+                chunk = int(max(4, min(256, (256 << 20) // (n_chains * stride * 8))))
+            chunk = max(1, min(int(chunk), n_steps))
+            shape = (n_chains, chunk, stride)
+            shms = [shared_memory.SharedMemory(create=True, size=int(np.prod(shape)) * 8) for _ in range(2)]
+            bufs = [np.ndarray(shape, dtype=np.float64, buffer=m.buf) for m in shms]
+            if n_workers is None:
+                try:
+                    import psutil
+                    cores = psutil.cpu_count(logical=False) or os.cpu_count()
+                except ImportError:
+                    cores = os.cpu_count()
+                n_workers = max(1, min(n_chains, cores - 1, len(os.sched_getaffinity(0)) - 1 or 1))
+            n_workers = max(1, min(int(n_workers), n_chains))
+            rf_param = {k: v for k, v in RF.__dict__.items() if k not in ('rng', '_last_size_idx')}
+            pool = mp.get_context('spawn').Pool(int(n_workers), initializer=_pool_init,
+                                                initargs=(rf_param, H, W, chain.update_in_region, np.asarray(chain.region_mask),
+                                                          [m.name for m in shms], shape))
+            n_chunks = (n_steps + chunk - 1) // chunk
+
+            def submit(k):
+                n = min(chunk, n_steps - k * chunk)
+                return pool.map_async(_pool_draw, [(c, k & 1, n, rf_states[c], chain_states[c]) for c in range(n_chains)])
+
+            pending = submit(0)
+            t0 = time.time()
+            for k in range(n_chunks):
+                n = min(chunk, n_steps - k * chunk)
+                si = np.empty((n_chains, n), np.int32); ce = np.empty((n_chains, n, 2), np.int32); u = np.empty((n_chains, n))
+                for slot, a, b, c_, st_rf, st_ch in pending.get():
+                    si[slot], ce[slot], u[slot] = a, b, c_
+                    rf_states[slot], chain_states[slot] = st_rf, st_ch
+                if k + 1 < n_chunks:
+                    pending = submit(k + 1)            # drawn on the host cores while the device steps chunk k
+                fields = torch.from_numpy(bufs[k & 1])
+                if n < chunk:
+                    fields = fields[:, :n].contiguous()
+                lo = k * chunk
+                loss[:, lo:lo + n], acc[:, lo:lo + n] = eng.run_replay(si, ce, u, fields.to(eng.dev))
+                blocks[:, lo:lo + n, 0:2] = ce
+                blocks[:, lo:lo + n, 2] = eng.bh[si]
+                blocks[:, lo:lo + n, 3] = eng.bw[si]
+                if progress:
+                    done = lo + n
+                    print(f"{n_chains} chains: {100 * done / n_steps:3.0f}% | chain-it/s: {n_chains * done / max(time.time() - t0, 1e-9):9.1f} | "
+                          f"acc: {acc[:, :done].mean():.4f}", file=sys.stdout, flush=True)
+        beds_out = eng.beds.double().cpu().numpy()
+        res = eng.resampled.cpu().numpy().astype(np.float64)
+    finally:
+        eng.close()
+        if pool is not None:
+            pool.terminate()
+            pool.join()
+        for m in shms:
+            m.close()
+            m.unlink()
+    out = []
+    for c in range(n_chains):
+        lc = np.concatenate([[loss0[c]], loss[c]])
+        sc = np.concatenate([[0.0], acc[c].astype(np.float64)])
+        bc = np.vstack([np.full((1, 4), np.nan), blocks[c]])
+        out.append((beds_out[c], lc.copy(), np.zeros(n_iter), lc, sc, res[c], bc))
+    return out, rf_states, chain_states
 
 
 def init_lsc_chain_by_instance(param_dict):

@@ -130,49 +130,126 @@ def _make_params(largeScaleChain, rf, i, initial_beds, rng_seeds, n_iters, outpu
     return chain_param, rf_param, run_param
 
 
+def _run_shard(lo, hi, largeScaleChain, rf, initial_beds, rng_seeds, n_iters, output_path, mode, batch, n_workers):
+    """The chains [lo, hi) of this rank: one libgsm_hip handle for all of them when they share n_iter (and, in Philox
+    mode, the Philox step); otherwise chain by chain through lsc_run_wrapper."""
+    base = Path(output_path) / 'LargeScaleChain'
+    idx = list(range(lo, hi))
+    same_len = len(set(int(n_iters[i]) for i in idx)) <= 1
+    if same_len and idx:
+        n_iter = int(n_iters[lo])
+        prevs = [_load_previous(_seed_folder(base, rng_seeds[i])) for i in idx]
+        beds = np.stack([np.asarray(p['bed'] if p else initial_beds[i], dtype=np.float64) for p, i in zip(prevs, idx)])
+        fresh = [np.random.default_rng(seed=rng_seeds[i]).bit_generator.state for i in idx]
+        rf_st = [p.get('rf_state', g) if p else g for p, g in zip(prevs, fresh)]
+        ch_st = [p.get('chain_state', g) if p else g for p, g in zip(prevs, fresh)]
+        steps0 = [int(p['philox']['step']) if (p and 'philox' in p) else 0 for p in prevs]
+        seeds = [int(rng_seeds[i]) for i in idx]
+        if mode == 'philox' and len(set(steps0)) == 1:
+            local = MCMC_gpu.run_many(largeScaleChain, rf, beds, seeds, n_iter, batch=batch, step0=steps0[0])
+            steps1 = [steps0[0] + n_iter - 1] * len(idx)
+        elif mode == 'replay':
+            local, rf_st, ch_st = MCMC_gpu.run_many_replay(largeScaleChain, rf, beds, rf_st, ch_st, n_iter,
+                                                           n_workers=n_workers if n_workers and n_workers > 0 else None)
+            steps1 = steps0
+        else:
+            local = None
+        if local is not None:
+            for k, i in enumerate(idx):
+                _save_segment(_seed_folder(base, rng_seeds[i]), local[k], n_iter, prevs[k], rf_st[k], ch_st[k],
+                              {'key': seeds[k] & 0xFFFFFFFFFFFFFFFF, 'step': steps1[k]})
+            return local
+    local = []
+    for i in idx:
+        cp, rp, runp = _make_params(largeScaleChain, rf, i, initial_beds, rng_seeds, n_iters, output_path)
+        cp['rng_mode'] = mode
+        _seed_folder(base, rng_seeds[i]).mkdir(parents=True, exist_ok=True)
+        local.append(lsc_run_wrapper(cp, rp, runp))
+    return local
+
+
+def _rank_main(rank, world, port, backend, payload_path, result_path):
+    """Body of one self-started rank (a fresh process): rendezvous on 127.0.0.1, run the shard, all-gather, rank 0 stores
+    the full result list for the parent."""
+    import os
+    import pickle
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), GSM_DIST_BACKEND=backend)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch
+    import torch.distributed as dist
+    parallel.init_distributed(backend)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(rank if torch.cuda.device_count() > rank else 0)
+    with open(payload_path, 'rb') as fh:
+        kw = pickle.load(fh)
+    res = largeScaleChain_mp(n_gpus=1, **kw)         # inside an initialised group: runs this rank's shard, gathers
+    if rank == 0:
+        with open(result_path, 'wb') as fh:
+            pickle.dump(res, fh, protocol=4)
+    parallel.barrier()
+    dist.destroy_process_group()
+
+
+def _self_launch(n_gpus, kw):
+    """Start n_gpus ranks of this driver (fresh processes: 'spawn'), one per GPU, as the reference's driver starts its own
+    pool workers (largeScaleChain_multiprocessing_GPU.py:47, :84-85); return rank 0's gathered result list."""
+    import os
+    import pickle
+    import socket
+    import tempfile
+    import torch
+    import torch.multiprocessing as tmp_mp
+    backend = os.environ.get('GSM_DIST_BACKEND') or ('nccl' if torch.cuda.device_count() >= n_gpus and torch.cuda.device_count() > 0 else 'gloo')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory(prefix='gsm_launch_') as td:
+        payload, result = os.path.join(td, 'payload.pkl'), os.path.join(td, 'result.pkl')
+        with open(payload, 'wb') as fh:
+            pickle.dump(kw, fh, protocol=4)
+        tmp_mp.spawn(_rank_main, args=(n_gpus, port, backend, payload, result), nprocs=n_gpus, join=True)   # raises if a rank fails
+        with open(result, 'rb') as fh:
+            return pickle.load(fh)
+
+
 def largeScaleChain_mp(n_chains, n_workers, largeScaleChain, rf, initial_beds, rng_seeds, n_iters,
-                       output_path='./Data/output', mode=None, batch=8, gather=True):
+                       output_path='./Data/output', mode=None, batch=8, gather=True, n_gpus=None):
     """Run n_chains large-scale chains and return the list of their result tuples (reference :22-104).
 
     mode 'replay' (default when largeScaleChain.rng_mode == 'replay'): every chain draws from its own NumPy
-    generators exactly as the reference's pool workers do, so results and checkpoint files equal the CPU driver's.
-    mode 'philox': all chains of this rank advance together in one handle with device-generated proposals."""
+    generators exactly as the reference's pool workers do, so results and checkpoint files equal the CPU driver's; all
+    chains of a rank share one handle, and `n_workers` host processes (the reference's argument; <= 0 or None: physical
+    cores - 1) draw the proposals of the next chunk while the device steps the current one.
+    mode 'philox': all chains of this rank advance together in one handle with device-generated proposals.
+
+    n_gpus: None = every visible GPU.  With more than one and no torch.distributed group in this process, the function
+    starts its own ranks (one fresh process per GPU, RCCL) -- the caller brings no launcher, like the reference's driver;
+    under torchrun (or inside such a rank) the initialised group is used and this process runs its shard."""
     tic = time.time()
     mode = mode or getattr(largeScaleChain, 'rng_mode', 'replay')
-    rank, _, world = parallel.dist_env()
+    import os
     import torch.distributed as dist
     sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    if not sharded:
-        rank, world = 0, 1
+    if not sharded and 'RANK' not in os.environ:
+        import torch
+        if n_gpus is None:
+            n_gpus = max(1, torch.cuda.device_count())
+        n_gpus = max(1, min(int(n_gpus), int(n_chains)))
+        if n_gpus > 1:
+            res = _self_launch(n_gpus, dict(n_chains=n_chains, n_workers=n_workers, largeScaleChain=largeScaleChain, rf=rf,
+                                            initial_beds=initial_beds, rng_seeds=rng_seeds, n_iters=n_iters,
+                                            output_path=output_path, mode=mode, batch=batch, gather=True))
+            print(f'Completed in {time.time() - tic:.2f} seconds')
+            return res
+    rank, world = (dist.get_rank(), dist.get_world_size()) if sharded else (0, 1)
     lo, hi = parallel.shard_bounds(n_chains, world, rank)
-    base = Path(output_path) / 'LargeScaleChain'
-    local = []
-    same_len = len(set(int(n_iters[i]) for i in range(lo, hi))) <= 1
-    if mode == 'philox' and same_len and hi > lo:
-        n_iter = int(n_iters[lo])
-        prevs = [_load_previous(_seed_folder(base, rng_seeds[i])) for i in range(lo, hi)]
-        steps0 = {int(p['philox']['step']) if (p and 'philox' in p) else 0 for p in prevs}
-        if len(steps0) == 1:
-            step0 = steps0.pop()
-            beds = np.stack([np.asarray(p['bed'] if p else initial_beds[i], dtype=np.float64)
-                             for p, i in zip(prevs, range(lo, hi))])
-            seeds = [int(rng_seeds[i]) for i in range(lo, hi)]
-            local = MCMC_gpu.run_many(largeScaleChain, rf, beds, seeds, n_iter, batch=batch, step0=step0)
-            for k, i in enumerate(range(lo, hi)):
-                g = np.random.default_rng(seed=rng_seeds[i]).bit_generator.state
-                p = prevs[k]
-                _save_segment(_seed_folder(base, rng_seeds[i]), local[k], n_iter, p,
-                              p.get('rf_state', g) if p else g, p.get('chain_state', g) if p else g,
-                              {'key': seeds[k] & 0xFFFFFFFFFFFFFFFF, 'step': step0 + n_iter - 1})
-    if not local:
-        for i in range(lo, hi):
-            cp, rp, runp = _make_params(largeScaleChain, rf, i, initial_beds, rng_seeds, n_iters, output_path)
-            cp['rng_mode'] = mode
-            _seed_folder(base, rng_seeds[i]).mkdir(parents=True, exist_ok=True)
-            local.append(lsc_run_wrapper(cp, rp, runp))
-    result = local
+    workers = n_workers
+    if workers and workers > 0 and world > 1:
+        workers = max(1, workers // world)
+    result = _run_shard(lo, hi, largeScaleChain, rf, initial_beds, rng_seeds, n_iters, output_path, mode, batch, workers)
     if sharded and gather:
-        result = _gather_results(local, n_chains, lo, hi)
+        result = _gather_results(result, n_chains, lo, hi)
     if rank == 0:
         print(f'Completed in {time.time() - tic:.2f} seconds')
     return result

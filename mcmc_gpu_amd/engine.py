@@ -130,6 +130,8 @@ class GsmEngine:
         """beds: (n_chains, H, W) array or cuda tensor.  Returns loss_cache[0] per chain (numpy)."""
         if isinstance(beds, torch.Tensor):
             b = beds.to(device=self.dev, dtype=self.state_dtype).contiguous()
+            if b.data_ptr() == beds.data_ptr():
+                b = b.clone()          # the engine updates its state in place: never alias the caller's tensor
         else:
             b = self._f64(beds).to(self.state_dtype)
         if tuple(b.shape) != (self.n_chains, self.H, self.W):

@@ -250,3 +250,58 @@ def test_highvel_boundary_on_device(golden_dir):
     m = Topography.get_highvel_boundary(g["velx"], g["vely"], float(g["threshold"]), g["grounded"], g["ocean"],
                                         float(g["distance_max"]), g["xx"], g["yy"], smooth_mode=int(g["smooth_mode"]))
     assert np.array_equal(m, g["mask_final"])
+
+
+def test_batched_replay_two_segments_files_equal_reference(golden_dir, tmp_path):
+    """largeScaleChain_mp in its default (replay) mode -- all chains of the rank in one handle, draws made by the host
+    pool -- twice in a row (resume from the seed folders): the folder of the F7 seed equals the reference wrapper's
+    files, and every chain equals its own single-chain lsc_run_wrapper run."""
+    g = np.load(golden_dir / "f7_wrapper_two_segments.npz")
+    seed = int(g["seed"])
+    prob, ch, rf = synthetic.template(64)
+    seeds = [seed, 777001, 777002]
+    beds = [prob["bed"].copy() for _ in seeds]
+    for _ in range(2):
+        res = driver.largeScaleChain_mp(3, 3, ch, rf, beds, seeds, [1000] * 3, output_path=str(tmp_path), n_gpus=1)
+    folder = tmp_path / "LargeScaleChain" / str(seed)[:6]
+    files = sorted(p.name for p in folder.iterdir())
+    assert [f for f in files if f != "RNGState_philox.txt"] == sorted(g["files"].tolist())
+    assert np.array_equal(np.load(folder / "bed_2k.npy"), g["bed_2k"])
+    with np.load(folder / "results_2k.npz") as r:
+        assert np.array_equal(r["steps"], g["res_steps"])
+        assert np.array_equal(r["blocks_used"], g["res_blocks_used"], equal_nan=True)
+        assert np.array_equal(r["resampled_times"], g["res_resampled_times"])
+        np.testing.assert_allclose(r["loss"], g["res_loss"], rtol=RTOL)
+    assert int(np.loadtxt(folder / "current_iter.txt")) == 2000
+    assert json.load(open(folder / "RNGState_chain.txt")) == json.loads(str(g["rng_state_chain"]))
+    assert json.load(open(folder / "RNGState_RandField.txt")) == json.loads(str(g["rng_state_randfield"]))
+    # one of the other chains against the single-chain wrapper, second segment included
+    alone = tmp_path / "alone" / "LargeScaleChain"
+    (alone / "777002").mkdir(parents=True)
+    for _ in range(2):
+        cp = deepcopy(ch.__dict__); cp["rng_seed"] = 777002; cp["initial_bed"] = prob["bed"].copy()
+        rp = deepcopy(rf.__dict__); rp["rng_seed"] = 777002
+        out = driver.lsc_run_wrapper(cp, rp, dict(n_iter=1000, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False,
+                                                  progress_bar=False, chain_id=2, tqdm_position=1, seed=777002, output_path=str(alone)))
+    for a, b in zip(res[2], out):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert np.array_equal(np.load(tmp_path / "LargeScaleChain" / "777002" / "bed_2k.npy"), np.load(alone / "777002" / "bed_2k.npy"))
+
+
+def test_largeScaleChain_mp_starts_its_own_ranks(tmp_path, monkeypatch):
+    """n_gpus=2 without a launcher: the driver spawns two ranks itself (here they share the box's one GPU, gloo instead of
+    RCCL), shards the chains, gathers -- same results as the single-process run, in both draw modes."""
+    monkeypatch.setenv("GSM_DIST_BACKEND", "gloo")
+    prob, ch, rf = synthetic.template(64)
+    seeds = [31, 32, 33, 34, 35]
+    beds = list(synthetic.initial_beds(prob, 5))
+    for mode in ("philox", "replay"):
+        one = driver.largeScaleChain_mp(5, 2, ch, rf, beds, seeds, [120] * 5, output_path=str(tmp_path / f"one_{mode}"), mode=mode, n_gpus=1)
+        two = driver.largeScaleChain_mp(5, 2, ch, rf, beds, seeds, [120] * 5, output_path=str(tmp_path / f"two_{mode}"), mode=mode, n_gpus=2)
+        assert len(two) == 5
+        for a, b in zip(one, two):
+            for x, y in zip(a, b):
+                assert np.array_equal(np.asarray(x, dtype=float), np.asarray(y, dtype=float), equal_nan=True)
+        for s in seeds:
+            assert np.array_equal(np.load(tmp_path / f"one_{mode}" / "LargeScaleChain" / str(s) / "bed_0k.npy"),
+                                  np.load(tmp_path / f"two_{mode}" / "LargeScaleChain" / str(s) / "bed_0k.npy"))
