@@ -59,6 +59,21 @@ def min_dist_from_mask(xx, yy, mask, device=None):
     return cKDTree(pts).query(np.array([xx.ravel(), yy.ravel()]).T)[0].reshape(xx.shape)
 
 
+_KGRID = {}
+
+
+def _wavenumber_grid(ny, nx, res):
+    """(k, 4 pi k^2) of MCMC.py:221-224, :239 for a block shape -- the same operations in the same order as the reference,
+    computed once per shape instead of once per proposal (they depend on nothing that is drawn)."""
+    key = (ny, nx, float(res))
+    g = _KGRID.get(key)
+    if g is None:
+        kyv, kxv = np.meshgrid(np.fft.fftfreq(ny, d=res) * 2 * np.pi, np.fft.fftfreq(nx, d=res) * 2 * np.pi, indexing="ij")
+        k = np.sqrt(kxv ** 2 + kyv ** 2) + 1e-10
+        g = _KGRID[key] = (k, 4 * np.pi * k ** 2)
+    return g
+
+
 def spectral_synthesis_field(RF, shape, res=1.0):
     """FFT spectral-synthesis realisation with the reference's draw order (MCMC.py:176-254): scale, nugget,
     range(s), two planes of normals, nugget normals.  Host generator of 'replay' mode."""
@@ -73,8 +88,7 @@ def spectral_synthesis_field(RF, shape, res=1.0):
         ry = rng.uniform(RF.range_min_y, RF.range_max_y)
     div = {"Gaussian": np.sqrt(3), "Exponential": 3.0}.get(RF.model_name, 2.0)
     a = np.sqrt((rx / div) * (ry / div))
-    kyv, kxv = np.meshgrid(np.fft.fftfreq(ny, d=res) * 2 * np.pi, np.fft.fftfreq(nx, d=res) * 2 * np.pi, indexing="ij")
-    k = np.sqrt(kxv ** 2 + kyv ** 2) + 1e-10
+    k, k2 = _wavenumber_grid(ny, nx, res)
     if RF.model_name == "Gaussian":
         S = np.exp(-0.5 * (a * k) ** 2)
     elif RF.model_name == "Exponential":
@@ -82,7 +96,7 @@ def spectral_synthesis_field(RF, shape, res=1.0):
     else:
         nu = RF.smoothness or 1.0
         S = ((4 * np.pi * math.gamma(nu + 1) * (2 * nu) ** nu) / (math.gamma(nu) * a ** (2 * nu))) * \
-            ((2 * nu / (a ** 2) + 4 * np.pi * k ** 2) ** (-nu - 1))
+            ((2 * nu / (a ** 2) + k2) ** (-nu - 1))
     white = rng.normal(size=(ny, nx)) + 1j * rng.normal(size=(ny, nx))
     fld = np.fft.ifft2(white * np.sqrt(S)).real
     fld = (fld - np.mean(fld)) / (np.std(fld) + 1e-12)
@@ -184,6 +198,21 @@ class RandField:
         return f * self.edge_masks[idx]
 
 
+def usable_cpus(cap=16):
+    """CPUs this process may really use: the affinity mask, the cgroup CPU quota (containers report every host core in
+    the mask), and a cap -- the default size of the host draw pool (the reference uses physical cores - 1,
+    largeScaleChain_multiprocessing_GPU.py:472)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 def draw_chunk(RF, rng, n, H, W, update_in_region, region_mask):
     """n Metropolis steps' worth of host draws in the reference's per-generator order: RF.rng gives the proposal block
     (MCMC.py:742-778 -> :176-254), `rng` (the chain's generator) the block centre -- rejection on region_mask when
@@ -211,42 +240,82 @@ def draw_chunk(RF, rng, n, H, W, update_in_region, region_mask):
     return size_idx, centre, u, fields
 
 
-# ---- host process pool that draws replay-mode proposals ahead of the device (run_many_replay) -------------------------
-_POOL = {}
+# ---- host processes that draw replay-mode proposals ahead of the device (run_many_replay) ------------------------------
+class DrawWorkers:
+    """n child processes (mcmc_gpu_amd/_draw_worker.py), each owning the NumPy generators of a fixed subset of chains."""
 
+    def __init__(self, n_workers, n_chains, rf_param, H, W, update_in_region, region_mask, shm_names, shm_shape,
+                 rf_states, chain_states):
+        import os
+        import subprocess
+        from pathlib import Path
+        from . import _draw_worker as proto
+        self.proto = proto
+        self.procs, self.fin, self.fout = [], [], []
+        env = dict(os.environ)
+        root = str(Path(__file__).resolve().parent.parent)
+        env['PYTHONPATH'] = root + (os.pathsep + env['PYTHONPATH'] if env.get('PYTHONPATH') else '')
+        env.setdefault('OMP_NUM_THREADS', '1'); env.setdefault('OPENBLAS_NUM_THREADS', '1')
+        n_workers = max(1, min(int(n_workers), n_chains))
+        try:
+            for w in range(n_workers):
+                p2c_r, p2c_w = os.pipe()
+                c2p_r, c2p_w = os.pipe()
+                self.procs.append(subprocess.Popen([sys.executable, '-m', 'mcmc_gpu_amd._draw_worker', str(p2c_r), str(c2p_w)],
+                                                   pass_fds=(p2c_r, c2p_w), env=env, stdin=subprocess.DEVNULL))
+                os.close(p2c_r); os.close(c2p_w)
+                self.fout.append(os.fdopen(p2c_w, 'wb')); self.fin.append(os.fdopen(c2p_r, 'rb'))
+            for w in range(n_workers):       # all workers are starting concurrently; now hand each its chains
+                slots = list(range(w, n_chains, n_workers))
+                proto.send(self.fout[w], dict(rf_param=rf_param, H=H, W=W, update_in_region=update_in_region, region_mask=region_mask,
+                                              shm_names=shm_names, shm_shape=shm_shape, slots=slots,
+                                              rf_states=[rf_states[c] for c in slots], chain_states=[chain_states[c] for c in slots]))
+            for w in range(n_workers):
+                if proto.recv(self.fin[w]) != 'ready':
+                    raise RuntimeError('draw worker did not start')
+        except BaseException:
+            self.close(kill=True)
+            raise
 
-def _pool_init(rf_param, H, W, update_in_region, region_mask, shm_names, shm_shape):
-    """Pool initializer: rebuild the RandField template once per worker, attach the shared field buffers."""
-    from multiprocessing import shared_memory
-    rf_param = dict(rf_param)
-    rf_param['rng_seed'] = 0
-    _POOL['rf'] = initiate_RF_by_instance(rf_param)
-    _POOL['geom'] = (H, W, update_in_region, region_mask)
-    _POOL['shm'] = [shared_memory.SharedMemory(name=nm) for nm in shm_names]
-    try:    # the parent owns (and unlinks) the segments: keep this process's resource tracker out of it (bpo-39959)
-        from multiprocessing import resource_tracker
-        for m in _POOL['shm']:
-            resource_tracker.unregister(m._name, 'shared_memory')
-    except Exception:
-        pass
-    _POOL['buf'] = [np.ndarray(shm_shape, dtype=np.float64, buffer=m.buf) for m in _POOL['shm']]
+    def request(self, which, n):
+        for f in self.fout:
+            self.proto.send(f, ('draw', which, n))
 
+    def collect(self):
+        out = []
+        for f in self.fin:
+            out.extend(self.proto.recv(f))
+        return out
 
-def _pool_draw(task):
-    """One chain's draws for one chunk: (chain slot, buffer index, n, RandField generator state, chain generator state)
-    -> (slot, size_idx, centre, u, new states); the masked fields go straight into the shared buffer
-    [n_chains, chunk, field_stride]."""
-    slot, which, n, rf_state, chain_state = task
-    rf = _POOL['rf']
-    rf.rng.bit_generator.state = rf_state
-    rng = np.random.default_rng(0)
-    rng.bit_generator.state = chain_state
-    H, W, upd, region = _POOL['geom']
-    si, ce, u, fields = draw_chunk(rf, rng, n, H, W, upd, region)
-    out = _POOL['buf'][which][slot]
-    for s, f in enumerate(fields):
-        out[s, :f.size] = f.ravel()
-    return slot, si, ce, u, rf.rng.bit_generator.state, rng.bit_generator.state
+    def states(self):
+        for f in self.fout:
+            self.proto.send(f, ('states',))
+        st = {}
+        for f in self.fin:
+            st.update(self.proto.recv(f))
+        return st
+
+    def close(self, kill=False):
+        for f in self.fout:
+            try:
+                if not kill:
+                    self.proto.send(f, ('quit',))
+                f.close()
+            except Exception:
+                pass
+        for p in self.procs:
+            try:
+                if kill:
+                    p.kill()
+                p.wait(timeout=10)
+            except Exception:
+                p.kill()
+        for f in self.fin:
+            try:
+                f.close()
+            except Exception:
+                pass
+        self.procs, self.fin, self.fout = [], [], []
 
 
 class chain_crf_gpu:
@@ -476,8 +545,6 @@ def run_many_replay(chain, RF, initial_beds, rf_states, chain_states, n_iter, ch
     chunk k+1 are made by a pool of host processes (they do not depend on the chains' state) while the device steps
     chunk k; the fields travel through shared memory.  Returns (list of chain.run(..., only_save_last_bed=True) tuples,
     final rf states, final chain states) -- results equal n independent chain_crf_gpu.run calls."""
-    import multiprocessing as mp
-    import os
     from multiprocessing import shared_memory
     import torch
     if not isinstance(RF, RandField):
@@ -508,52 +575,51 @@ def run_many_replay(chain, RF, initial_beds, rf_states, chain_states, n_iter, ch
             shms = [shared_memory.SharedMemory(create=True, size=int(np.prod(shape)) * 8) for _ in range(2)]
             bufs = [np.ndarray(shape, dtype=np.float64, buffer=m.buf) for m in shms]
             if n_workers is None:
-                try:
-                    import psutil
-                    cores = psutil.cpu_count(logical=False) or os.cpu_count()
-                except ImportError:
-                    cores = os.cpu_count()
-                n_workers = max(1, min(n_chains, cores - 1, len(os.sched_getaffinity(0)) - 1 or 1))
+                n_workers = max(1, usable_cpus() - 1)
             n_workers = max(1, min(int(n_workers), n_chains))
             rf_param = {k: v for k, v in RF.__dict__.items() if k not in ('rng', '_last_size_idx')}
-            pool = mp.get_context('spawn').Pool(int(n_workers), initializer=_pool_init,
-                                                initargs=(rf_param, H, W, chain.update_in_region, np.asarray(chain.region_mask),
-                                                          [m.name for m in shms], shape))
+            pool = DrawWorkers(n_workers, n_chains, rf_param, H, W, chain.update_in_region, np.asarray(chain.region_mask),
+                               [m.name for m in shms], shape, rf_states, chain_states)
             n_chunks = (n_steps + chunk - 1) // chunk
-
-            def submit(k):
-                n = min(chunk, n_steps - k * chunk)
-                return pool.map_async(_pool_draw, [(c, k & 1, n, rf_states[c], chain_states[c]) for c in range(n_chains)])
-
-            pending = submit(0)
+            pool.request(0, min(chunk, n_steps))
             t0 = time.time()
+            t_wait = t_dev = 0.0
             for k in range(n_chunks):
                 n = min(chunk, n_steps - k * chunk)
                 si = np.empty((n_chains, n), np.int32); ce = np.empty((n_chains, n, 2), np.int32); u = np.empty((n_chains, n))
-                for slot, a, b, c_, st_rf, st_ch in pending.get():
+                tw = time.time()
+                drawn = pool.collect()
+                t_wait += time.time() - tw
+                for slot, a, b, c_ in drawn:
                     si[slot], ce[slot], u[slot] = a, b, c_
-                    rf_states[slot], chain_states[slot] = st_rf, st_ch
-                if k + 1 < n_chunks:
-                    pending = submit(k + 1)            # drawn on the host cores while the device steps chunk k
+                if k + 1 < n_chunks:                   # drawn on the host cores while the device steps chunk k
+                    pool.request((k + 1) & 1, min(chunk, n_steps - (k + 1) * chunk))
                 fields = torch.from_numpy(bufs[k & 1])
                 if n < chunk:
                     fields = fields[:, :n].contiguous()
                 lo = k * chunk
+                tw = time.time()
                 loss[:, lo:lo + n], acc[:, lo:lo + n] = eng.run_replay(si, ce, u, fields.to(eng.dev))
+                t_dev += time.time() - tw
                 blocks[:, lo:lo + n, 0:2] = ce
                 blocks[:, lo:lo + n, 2] = eng.bh[si]
                 blocks[:, lo:lo + n, 3] = eng.bw[si]
                 if progress:
                     done = lo + n
                     print(f"{n_chains} chains: {100 * done / n_steps:3.0f}% | chain-it/s: {n_chains * done / max(time.time() - t0, 1e-9):9.1f} | "
-                          f"acc: {acc[:, :done].mean():.4f}", file=sys.stdout, flush=True)
+                          f"acc: {acc[:, :done].mean():.4f} | waited for draws {t_wait:.2f} s, upload + device {t_dev:.2f} s",
+                          file=sys.stdout, flush=True)
+            st = pool.states()
+            rf_states = [st[c][0] for c in range(n_chains)]
+            chain_states = [st[c][1] for c in range(n_chains)]
+            pool.close()
+            pool = None
         beds_out = eng.beds.double().cpu().numpy()
         res = eng.resampled.cpu().numpy().astype(np.float64)
     finally:
         eng.close()
         if pool is not None:
-            pool.terminate()
-            pool.join()
+            pool.close(kill=True)
         for m in shms:
             m.close()
             m.unlink()

@@ -208,41 +208,46 @@ def test_highvel_boundary_equals_reference(golden_dir):
     assert 0 < m.sum() < m.size
 
 
-def test_pool_draws_equal_serial_draws():
-    """run_many_replay's host pool (spawned processes, generator states handed from chunk to chunk, fields through shared
-    memory) produces exactly the draws chain_crf_gpu._draw_chunk makes in-process -- the reference's per-generator order."""
-    import multiprocessing as mp
+def test_draw_workers_equal_serial_draws():
+    """run_many_replay's host draw workers (child processes owning the generators of their chains, fields through shared
+    memory, two chunks into alternating buffers) produce exactly the draws chain_crf_gpu._draw_chunk makes in-process --
+    the reference's per-generator order -- and hand back the generators' final states."""
     from multiprocessing import shared_memory
     prob, ch, rf = synthetic.template(64)
     H, W = prob["bed"].shape
-    seeds, n, chunks = [11, 12, 13], 5, 2
+    seeds, n, chunks = [11, 12, 13], 5, 3
     stride = int(rf.pairs[0].max() * rf.pairs[1].max())
     shape = (len(seeds), n, stride)
     shms = [shared_memory.SharedMemory(create=True, size=int(np.prod(shape)) * 8) for _ in range(2)]
+    pool = None
     try:
         bufs = [np.ndarray(shape, dtype=np.float64, buffer=m.buf) for m in shms]
         rf_param = {k: v for k, v in rf.__dict__.items() if k not in ("rng", "_last_size_idx")}
-        with mp.get_context("spawn").Pool(2, initializer=MCMC_gpu._pool_init,
-                                          initargs=(rf_param, H, W, ch.update_in_region, np.asarray(ch.region_mask),
-                                                    [m.name for m in shms], shape)) as pool:
-            st = [np.random.default_rng(seed=s).bit_generator.state for s in seeds]
-            rf_st, ch_st = list(st), list(st)
-            got = [[] for _ in seeds]
-            for k in range(chunks):
-                for slot, si, ce, u, a, b in pool.map(MCMC_gpu._pool_draw, [(c, k & 1, n, rf_st[c], ch_st[c]) for c in range(len(seeds))]):
-                    rf_st[slot], ch_st[slot] = a, b
-                    got[slot].append((si, ce, u, bufs[k & 1][slot].copy()))
+        st = [np.random.default_rng(seed=s).bit_generator.state for s in seeds]
+        pool = MCMC_gpu.DrawWorkers(2, len(seeds), rf_param, H, W, ch.update_in_region, np.asarray(ch.region_mask),
+                                    [m.name for m in shms], shape, st, st)
+        got = [[] for _ in seeds]
+        pool.request(0, n)
+        for k in range(chunks):
+            res = pool.collect()
+            for slot, si, ce, u in res:
+                got[slot].append((si, ce, u, bufs[k & 1][slot].copy()))
+            if k + 1 < chunks:
+                pool.request((k + 1) & 1, n)
+        states = pool.states()
+        pool.close(); pool = None
         for c, s in enumerate(seeds):
-            rp = dict(rf_param, rng_seed=s)
-            rf_c = MCMC_gpu.initiate_RF_by_instance(rp)
+            rf_c = MCMC_gpu.initiate_RF_by_instance(dict(rf_param, rng_seed=s))
             rng = np.random.default_rng(seed=s)
             for k in range(chunks):
                 si, ce, u, fields = MCMC_gpu.draw_chunk(rf_c, rng, n, H, W, ch.update_in_region, ch.region_mask)
                 assert np.array_equal(si, got[c][k][0]) and np.array_equal(ce, got[c][k][1]) and np.array_equal(u, got[c][k][2])
                 for j, f in enumerate(fields):
                     assert np.array_equal(got[c][k][3][j, :f.size], f.ravel())
-            assert rf_c.rng.bit_generator.state == rf_st[c] and rng.bit_generator.state == ch_st[c]
+            assert states[c] == (rf_c.rng.bit_generator.state, rng.bit_generator.state)
     finally:
+        if pool is not None:
+            pool.close(kill=True)
         for m in shms:
             m.close()
             m.unlink()
