@@ -216,6 +216,46 @@ int gsm_cholesky_upper(gsm_handle h, double* a, int32_t n, int64_t ld, double ji
  * The reference has no such generator (README.md:21-23 lists it as future work); this is north_star's. */
 int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* const* factors, void* stream);
 
+/* ---- small-scale chain (chain_sgs, gstatsMCMC/MCMC.py:1445-1911) ------------------------------------------------------
+ * Sequential Gaussian simulation of one block per chain with ordinary kriging on octant-searched neighbours.
+ *   grids    [dev, n_chains*H*W] in/out  the conditioning grid of each chain (`bed_tosim`, MCMC.py:1766-1771): values
+ *                                       everywhere except NaN at the cells to simulate; on return the block's cells hold
+ *                                       the simulated values (`newsim`, MCMC.py:1774)
+ *   zcond    [dev, H*W] or NULL         if given, the block's cells are first set from it (the conditioning data of the
+ *                                       block, NaN where there is none: z_cond_bed, MCMC.py:1771)
+ *   windows  [dev, n_chains*4]          (row0, row1, col0, col1) of each chain's block; at most 1024 cells
+ *   x_axis [dev, W], y_axis [dev, H]    coordinates of the columns / rows (the grid must be axis-aligned: xx[i][j] = x_axis[j])
+ *   lag_cov  [dev, (4hw+1)^2]           covariance at the integer lag (di, dj), -2hw <= di, dj <= 2hw, row-major: the caller
+ *                                       evaluates the variogram model (covariance.py:4-28 through make_sigma / make_rho,
+ *                                       _krige.py:105-143) once per lag; hw = ceil(radius / |x_axis[1] - x_axis[0]|) <= 16
+ *   cell_off [dev, n_chains+1], cells [dev, total*2]   the (row, col) of each chain's cells in simulation order -- the
+ *                                       caller's rng.shuffle (MCMC.py:128); every cell must lie inside the chain's window
+ *   z        [dev, total]               one standard normal per listed cell (used only if the cell is simulated):
+ *                                       rng.normal(est, sqrt(var)) = est + sqrt(var) * z (MCMC.py:165)
+ *   trace    [dev, total*3] or NULL     (number of neighbours, kriging estimate, kriging variance) per cell; -1 neighbours =
+ *                                       cell was conditioned already
+ * num_points in [8, 48] (num_points / 8 per octant).  The kriging systems are solved by elimination with partial pivoting
+ * where the reference calls numpy.linalg.lstsq: estimates agree to ~1e-10 relative, not bit for bit.  A cell with no
+ * neighbour within `radius` (the reference would widen the search by 100 km, MCMC.py:152-156) returns GSM_E_UNSUPPORTED.
+ * Synchronises the stream.
+ * Replaces: sgs (MCMC.py:91-173), neighbors (gstatsim_custom/neighbors.py:4-64), ok_solve (gstatsim_custom/_krige.py:5-44). */
+int gsm_sgs_blocks(gsm_handle h, double* grids, const double* zcond, const int32_t* windows, const double* x_axis,
+                   const double* y_axis, const double* lag_cov, int32_t hw, double radius, int32_t num_points, double sill,
+                   const int32_t* cell_off, const int32_t* cells, const double* z, double* trace, void* stream);
+
+/* Loss and thickness guard of proposed beds over the whole grid: loss[c] = nansum(residual(bed_c + trend)^2 where
+ * mc_mask == 1) / (2 sigma^2), bad[c] = number of cells with update_mask == 1 (set it to grounded_ice_mask) and
+ * surf - (bed_c + trend) <= 0.  beds [dev, n_chains*H*W], trend [dev, H*W] or NULL, loss [dev, n_chains], bad [dev, n_chains].
+ * Replaces: chain_sgs.run's per-iteration loss and guard (MCMC.py:1781-1795). */
+int gsm_sgs_loss(gsm_handle h, const double* beds, const double* trend, double* loss, int32_t* bad, void* stream);
+
+/* Accept / reject bookkeeping of one small-scale iteration: where accept[c] != 0 the block of chain c is copied from
+ * `next` into `cur` and resampled counts of the block are incremented (MCMC.py:1803-1812); elsewhere the block of `next`
+ * is restored from `cur`.  cur, next [dev, n_chains*H*W], resampled [dev, n_chains*H*W], windows as in gsm_sgs_blocks,
+ * accept [dev, n_chains]. */
+int gsm_sgs_commit(gsm_handle h, double* cur, double* next, uint32_t* resampled, const int32_t* windows,
+                   const uint8_t* accept, void* stream);
+
 /* Setup-time distance transform: dist[i] = Euclidean distance from cell i (coordinates xx[i], yy[i]) to the nearest
  * cell with mask[i] != 0, all [dev, H*W].  Exact (brute force over the masked cells, same dx*dx + dy*dy, sqrt
  * arithmetic as the KD-tree query).  Synchronises the stream.

@@ -33,6 +33,15 @@ __all__ = ["RandField", "chain_crf_gpu", "init_lsc_chain_by_instance", "initiate
            "spectral_synthesis_field", "run_many", "run_many_replay", "draw_chunk", "min_dist_from_mask"]
 
 
+def __getattr__(name):
+    """The small-scale chain lives in mcmc_gpu_amd.sgs; it is reachable from this namespace like in the reference's
+    (gstatsMCMC.MCMC holds both chains), imported on first use."""
+    if name in ("chain_sgs_gpu", "init_msc_chain_by_instance", "run_many_sgs"):
+        from . import sgs
+        return getattr(sgs, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
 def min_dist_from_mask(xx, yy, mask, device=None):
     """Distance from every cell to the nearest True cell of `mask` (Utilities.py:21-24) -- SETUP-time code, run once per
     problem, not part of the sampler's hot path.

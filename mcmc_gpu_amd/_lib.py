@@ -16,7 +16,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libgsm_hip.so"
 HEADER = PKG_DIR.parent / "include" / "gsm.h"
-SOURCES = ["gsm_api.hip", "gsm_version.hip", "step_kernel.hip", "step_flux_kernel.hip", "chain_fused_kernel.hip", "proposal_kernel.hip", "cholesky_kernel.hip"]
+SOURCES = ["gsm_api.hip", "gsm_version.hip", "step_kernel.hip", "step_flux_kernel.hip", "chain_fused_kernel.hip", "proposal_kernel.hip", "cholesky_kernel.hip", "sgs_kernel.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-Wno-unused-value", "-Wno-unused-result"]
 # per-file extras.  step_flux_kernel: without machine LICM the fp64 polynomial constants of exp() are materialised at
@@ -166,6 +166,9 @@ def load() -> C.CDLL:
     lib.gsm_cov_assemble.argtypes = [vp, i32, i32, dbl, C.POINTER(Vario), vp, vp, i64, vp]
     lib.gsm_cholesky_upper.argtypes = [vp, vp, i32, i64, dbl, vp]
     lib.gsm_set_factors.argtypes = [vp, i32, C.POINTER(vp), vp]
+    lib.gsm_sgs_blocks.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, dbl, i32, dbl, vp, vp, vp, vp, vp]
+    lib.gsm_sgs_loss.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.gsm_sgs_commit.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.gsm_min_dist_from_mask.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.gsm_debug_stream_copy.argtypes = [vp, vp, i64, vp]
     lib.gsm_philox_selftest.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]

@@ -715,6 +715,56 @@ extern "C" int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* co
   return GSM_OK;
 }
 
+extern "C" int gsm_sgs_blocks(gsm_handle h, double* grids, const double* zcond, const int32_t* windows, const double* x_axis,
+                              const double* y_axis, const double* lag_cov, int32_t hw, double radius, int32_t num_points, double sill,
+                              const int32_t* cell_off, const int32_t* cells, const double* z, double* trace, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!grids || !windows || !x_axis || !y_axis || !lag_cov || !cell_off || !cells || !z)
+    return fail(h, GSM_E_ARG, "gsm_sgs_blocks: NULL pointer");
+  if (hw < 1 || hw > 16) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_blocks: search half-width (radius / grid spacing) must be in [1, 16] cells");
+  if (num_points < 8 || num_points > 48) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_blocks: num_points must be in [8, 48]");
+  if (!(radius > 0.0)) return fail(h, GSM_E_ARG, "gsm_sgs_blocks: radius must be > 0");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  SgsArgs a{};
+  a.H = h->H; a.W = h->W; a.n_chains = h->n_chains;
+  a.grid = grids; a.zcond = zcond; a.win = windows; a.xs = x_axis; a.ys = y_axis; a.lag = lag_cov;
+  a.hw = hw; a.m = 2 * hw; a.num_points = num_points; a.radius = radius; a.sill = sill;
+  a.cell_off = cell_off; a.cells = cells; a.z = z; a.trace = trace; a.err = h->d_err;
+  HIPCHK(h, launch_sgs_blocks(a, st));
+  int32_t flag = 0;
+  HIPCHK(h, hipMemcpyAsync(&flag, h->d_err, sizeof(flag), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (flag) {
+    hipMemsetAsync(h->d_err, 0, sizeof(int32_t), st);
+    hipStreamSynchronize(st);
+    if (flag & 4) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_blocks: a cell has no conditioning value within the search radius (the reference's "
+                                                     "radius-widening fallback, MCMC.py:152-156, is not built)");
+    if (flag & 8) return fail(h, GSM_E_DEVICE_DATA, "gsm_sgs_blocks: singular kriging system");
+    return fail(h, GSM_E_DEVICE_DATA, "gsm_sgs_blocks: window outside the grid / larger than 1024 cells, or a listed cell outside its window");
+  }
+  return GSM_OK;
+}
+
+extern "C" int gsm_sgs_loss(gsm_handle h, const double* beds, const double* trend, double* loss, int32_t* bad, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_sgs_loss: call gsm_set_static first");
+  if (h->f32_state) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_loss: fp64 beds only");
+  if (!beds || !loss || !bad) return fail(h, GSM_E_ARG, "gsm_sgs_loss: NULL pointer");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_sgs_loss(h->S, h->n_chains, beds, trend, loss, bad, (hipStream_t)stream));
+  return GSM_OK;
+}
+
+extern "C" int gsm_sgs_commit(gsm_handle h, double* cur, double* next, uint32_t* resampled, const int32_t* windows,
+                              const uint8_t* accept, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!cur || !next || !resampled || !windows || !accept) return fail(h, GSM_E_ARG, "gsm_sgs_commit: NULL pointer");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_sgs_commit(h->H, h->W, h->n_chains, cur, next, resampled, windows, accept, (hipStream_t)stream));
+  return GSM_OK;
+}
+
 extern "C" int gsm_min_dist_from_mask(gsm_handle h, const double* xx, const double* yy, const uint8_t* mask,
                                       double* dist, void* stream) {
   if (!h) return GSM_E_ARG;

@@ -128,6 +128,29 @@ struct CholArgs {
   double* zbuf;                    // sum over groups of Npad * ppad doubles
 };
 
+// small-scale chain: sequential Gaussian simulation of one block per chain (sgs_kernel.hip)
+struct SgsArgs {
+  int H, W, n_chains;
+  double* grid;            // [n_chains][H*W] in/out: the conditioning grid; the window's cells are rewritten
+  const double* zcond;     // [H*W] or nullptr: initial content of the window cells (conditioning data, NaN elsewhere)
+  const int32_t* win;      // [n_chains*4] r0, r1, c0, c1 of the simulated block
+  const double* xs;        // [W] x coordinate of every column
+  const double* ys;        // [H] y coordinate of every row
+  const double* lag;       // [(2m+1)^2] covariance at integer lag (di, dj), m = 2 * hw
+  int hw, m, num_points;
+  double radius, sill;
+  const int32_t* cell_off; // [n_chains+1]
+  const int32_t* cells;    // [total*2] (i, j) in simulation order
+  const double* z;         // [total] standard normals
+  double* trace;           // optional [total*3]: (neighbours, estimate, variance)
+  int32_t* err;
+};
+hipError_t launch_sgs_blocks(const SgsArgs& a, hipStream_t st);
+hipError_t launch_sgs_loss(const StaticFields& S, int n_chains, const double* beds, const double* trend, double* loss, int32_t* bad,
+                           hipStream_t st);
+hipError_t launch_sgs_commit(int H, int W, int n_chains, double* cur, double* next, uint32_t* resampled, const int32_t* win,
+                             const uint8_t* accept, hipStream_t st);
+
 // launchers (defined next to their kernels)
 hipError_t launch_propose_cholesky(const ProposeArgs& a, const CholArgs& c, hipStream_t st);
 hipError_t launch_cholesky_upper(double* A, int n, int ld, double jitter, int* d_info, hipStream_t st);

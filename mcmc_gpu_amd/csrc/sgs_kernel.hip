@@ -1,0 +1,280 @@
+// Small-scale chain on gfx950: sequential Gaussian simulation of one block per chain, and the chain's full-grid loss.
+//
+// Replaces, for a batch of chains (one 64-lane workgroup = one wavefront per chain):
+//   sgs                      gstatsMCMC/MCMC.py:91-173   (cell loop :135-168)
+//   neighbors (octant search) gstatsMCMC/gstatsim_custom/neighbors.py:4-64
+//   ok_solve                 gstatsMCMC/gstatsim_custom/_krige.py:5-44
+//   chain.loss on the proposed bed + thickness guard  MCMC.py:1781-1795 (loss :1021-1044, Topography.py:592-600)
+//
+// The random numbers are the caller's (replay: NumPy's PCG64 on the host, in the reference's order): the order in which
+// the block's cells are visited (rng.shuffle, MCMC.py:128) and one standard normal per simulated cell
+// (rng.normal(est, sqrt(var)) = est + sqrt(var) * z, MCMC.py:165).
+//
+// Per cell, in the given order, if the cell is not conditioned yet:
+//   1 octant search: every grid cell within +-hw of the cell that holds a value (everything outside the block does: the
+//     current bed; inside the block the conditioning data and the cells simulated so far) and lies closer than `radius` is
+//     put into one of eight 45-degree sectors, (b pi/4, (b+1) pi/4], b = -4..3, of atan2(y0 - y, x0 - x).  The sector is
+//     decided from the signs and magnitudes of the two coordinate differences -- exactly what numpy.arctan2 gives on the
+//     sector boundaries (multiples of pi/4 are hit only by cells on the axes and diagonals, where arctan2 returns the
+//     boundary value bit for bit; checked on the host).  Per sector the num_points / 8 nearest, ties by window position
+//     (NumPy's masked C order followed by a stable sort; numpy.argsort's default sort is stable below 17 elements).
+//   2 ordinary kriging: (n+1) x (n+1) system [Sigma 1; 1^T 0] w = [rho; 1], covariances from a table indexed by the integer
+//     lag between two cells (the host evaluates the reference's covariance model -- scipy's Bessel K for Matern -- once per
+//     lag), solved in LDS by Gauss-Jordan elimination with partial pivoting in fp64 (the reference calls numpy.linalg.lstsq,
+//     an SVD solve: same solution for these non-singular systems, different rounding -- the stated tolerance of this path).
+//   3 value = est + sqrt(|var|) * z; the cell becomes conditioning data for the cells after it.
+// Limits: hw <= 16 (search window 33 x 33), num_points <= 48, window (block) cells <= 1024.  A cell without any neighbour
+// inside `radius` would make the reference grow the radius by 100 km (MCMC.py:152-156): not built, reported as an error.
+#include "gsm_internal.h"
+#include "residual_device.h"
+#include <math.h>
+
+namespace gsm {
+
+constexpr int kSgsMaxHw = 16;
+constexpr int kSgsMaxCand = (2 * kSgsMaxHw + 1) * (2 * kSgsMaxHw + 1);   // 1089
+constexpr int kSgsMaxPts = 48;
+constexpr int kSgsStride = kSgsMaxPts + 3;                                // row stride of the augmented matrix
+constexpr int kSgsMaxWin = 1024;
+
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// sector b + 4 in 0..7 of atan2(dy, dx) in (b pi/4, (b+1) pi/4]
+__device__ __forceinline__ int octant(double dy, double dx) {
+  if (dy == 0.0) return (dx < 0.0) ? 7 : 3;                    // angle pi -> b = 3; angle 0 -> b = -1
+  const double ay = fabs(dy), ax = fabs(dx);
+  if (dy > 0.0) {
+    if (dx > 0.0) return (ay <= ax) ? 4 : 5;                   // (0, pi/4] | (pi/4, pi/2)
+    if (dx == 0.0) return 5;                                   // pi/2
+    return (ay >= ax) ? 6 : 7;                                 // (pi/2, 3pi/4] | (3pi/4, pi)
+  }
+  if (dx > 0.0) return (ay < ax) ? 3 : 2;                      // (-pi/4, 0) | (-pi/2, -pi/4]
+  if (dx == 0.0) return 1;                                     // -pi/2 -> (-3pi/4, -pi/2]
+  return (ay > ax) ? 1 : 0;                                    // (-3pi/4, -pi/2) | (-pi, -3pi/4]
+}
+
+__global__ __launch_bounds__(64) void sgs_blocks_kernel(const SgsArgs a) {
+  __shared__ double cand_d[kSgsMaxCand];
+  __shared__ int8_t cand_s[kSgsMaxCand];
+  __shared__ double overlay[kSgsMaxWin];
+  __shared__ double A[(kSgsMaxPts + 1) * kSgsStride];
+  __shared__ double nb_val[kSgsMaxPts];
+  __shared__ int nb_i[kSgsMaxPts], nb_j[kSgsMaxPts];
+  const int chain = blockIdx.x, lane = threadIdx.x;
+  const int H = a.H, W = a.W;
+  double* __restrict__ g = a.grid + (size_t)chain * H * W;
+  const int r0 = a.win[4 * chain], r1 = a.win[4 * chain + 1], c0 = a.win[4 * chain + 2], c1 = a.win[4 * chain + 3];
+  const int wh = r1 - r0, ww = c1 - c0;
+  if (r0 < 0 || c0 < 0 || r1 > H || c1 > W || wh < 0 || ww < 0 || wh * ww > kSgsMaxWin) {
+    if (lane == 0) atomicOr(a.err, 1);
+    return;
+  }
+  // the block's cells: conditioning data (or NaN) now, simulated values as the loop goes; lives in LDS until the end
+  for (int p = lane; p < wh * ww; p += 64) {
+    const int gi = (r0 + p / ww) * W + c0 + p % ww;
+    overlay[p] = a.zcond ? a.zcond[gi] : g[gi];
+  }
+  __syncthreads();
+  auto value_at = [&](int i, int j) -> double {
+    if (i >= r0 && i < r1 && j >= c0 && j < c1) return overlay[(i - r0) * ww + (j - c0)];
+    return g[i * W + j];
+  };
+  const int hw = a.hw, k8 = a.num_points / 8;
+  const int side = 2 * hw + 1, m = a.m, lag_side = 2 * m + 1;
+  auto lag_cov = [&](int di, int dj) { return a.lag[(di + m) * lag_side + dj + m]; };
+  const int k_lo = a.cell_off[chain], k_hi = a.cell_off[chain + 1];
+  for (int k = k_lo; k < k_hi; ++k) {
+    const int i0 = a.cells[2 * k], j0 = a.cells[2 * k + 1];
+    if (i0 < r0 || i0 >= r1 || j0 < c0 || j0 >= c1) { if (lane == 0) atomicOr(a.err, 2); continue; }
+    const int op = (i0 - r0) * ww + (j0 - c0);
+    if (!isnan(overlay[op])) {                       // conditioned already: nothing drawn for it (MCMC.py:141)
+      if (a.trace && lane == 0) { a.trace[3 * k] = -1.0; a.trace[3 * k + 1] = overlay[op]; a.trace[3 * k + 2] = 0.0; }
+      continue;
+    }
+    // ---- 1 candidates of the search window -> (distance, sector) ------------------------------------
+    const double x0 = a.xs[j0], y0 = a.ys[i0];
+    for (int p = lane; p < side * side; p += 64) {
+      const int i = i0 - hw + p / side, j = j0 - hw + p % side;
+      int sec = -1;
+      double d = 0.0;
+      if (i >= 0 && i < H && j >= 0 && j < W) {
+        const double v = value_at(i, j);
+        if (!isnan(v)) {
+          const double dx = x0 - a.xs[j], dy = y0 - a.ys[i];
+          d = sqrt(dx * dx + dy * dy);
+          if (d < a.radius) sec = octant(dy, dx);
+        }
+      }
+      cand_d[p] = d;
+      cand_s[p] = (int8_t)sec;
+    }
+    __syncthreads();
+    // per sector, in ascending (distance, window position): extract up to k8 points
+    int n = 0;
+    for (int s = 0; s < 8; ++s) {
+      double prev_d = -1.0;
+      int prev_p = -1;
+      for (int r = 0; r < k8; ++r) {
+        double best_d = INFINITY;
+        int best_p = 0x7fffffff;
+        for (int p = lane; p < side * side; p += 64) {
+          if (cand_s[p] != s) continue;
+          const double d = cand_d[p];
+          if (d < prev_d || (d == prev_d && p <= prev_p)) continue;        // taken in an earlier round
+          if (d < best_d || (d == best_d && p < best_p)) { best_d = d; best_p = p; }
+        }
+        const double wd = wave_min_f64(best_d);
+        if (wd == INFINITY) break;                                          // sector exhausted
+        const int wp = wave_min_i32((best_d == wd) ? best_p : 0x7fffffff);
+        if (lane == 0) {
+          const int i = i0 - hw + wp / side, j = j0 - hw + wp % side;
+          nb_i[n] = i; nb_j[n] = j; nb_val[n] = value_at(i, j);
+        }
+        prev_d = wd; prev_p = wp;
+        ++n;
+      }
+    }
+    __syncthreads();
+    if (n == 0) {
+      if (lane == 0) { atomicOr(a.err, 4); overlay[op] = NAN; }
+      continue;
+    }
+    // ---- 2 ordinary kriging system, Gauss-Jordan with partial pivoting ---------------------------------
+    const int N = n + 1;
+    for (int e = lane; e < N * (N + 1); e += 64) {
+      const int ra = e / (N + 1), cb = e % (N + 1);
+      double v;
+      if (cb == N) v = (ra < n) ? lag_cov(nb_i[ra] - i0, nb_j[ra] - j0) : 1.0;      // rho | 1
+      else if (ra < n && cb < n) v = lag_cov(nb_i[ra] - nb_i[cb], nb_j[ra] - nb_j[cb]);
+      else v = (ra == n && cb == n) ? 0.0 : 1.0;
+      A[ra * kSgsStride + cb] = v;
+    }
+    __syncthreads();
+    const double rho_l = (lane < n) ? A[lane * kSgsStride + N] : 0.0;            // kept: the elimination overwrites it
+    bool singular = false;
+    for (int kk = 0; kk < N; ++kk) {
+      const double mine = (lane >= kk && lane < N) ? fabs(A[lane * kSgsStride + kk]) : -1.0;
+      const double mx = -wave_min_f64(-mine);
+      const int piv = wave_min_i32((mine == mx) ? lane : 0x7fffffff);
+      if (!(mx > 0.0)) { singular = true; break; }
+      if (piv != kk && lane <= N) {
+        const double t = A[kk * kSgsStride + lane];
+        A[kk * kSgsStride + lane] = A[piv * kSgsStride + lane];
+        A[piv * kSgsStride + lane] = t;
+      }
+      __syncthreads();
+      if (lane < N && lane != kk) {
+        const double f = A[lane * kSgsStride + kk] / A[kk * kSgsStride + kk];
+        for (int c = kk + 1; c <= N; ++c) A[lane * kSgsStride + c] -= f * A[kk * kSgsStride + c];
+        A[lane * kSgsStride + kk] = 0.0;
+      }
+      __syncthreads();
+    }
+    if (singular) {
+      if (lane == 0) { atomicOr(a.err, 8); overlay[op] = NAN; }
+      __syncthreads();
+      continue;
+    }
+    const double w_l = (lane < n) ? A[lane * kSgsStride + N] / A[lane * kSgsStride + lane] : 0.0;
+    const double v_l = (lane < n) ? nb_val[lane] : 0.0;
+    const double local_mean = wave_sum_f64(v_l) / (double)n;
+    const double est = local_mean + wave_sum_f64((lane < n) ? w_l * (v_l - local_mean) : 0.0);
+    double var = a.sill - wave_sum_f64(w_l * rho_l);
+    var = fabs(var);
+    if (lane == 0) {
+      overlay[op] = est + sqrt(var) * a.z[k];
+      if (a.trace) { a.trace[3 * k] = (double)n; a.trace[3 * k + 1] = est; a.trace[3 * k + 2] = var; }
+    }
+    __syncthreads();
+  }
+  for (int p = lane; p < wh * ww; p += 64) g[(r0 + p / ww) * W + c0 + p % ww] = overlay[p];
+}
+
+hipError_t launch_sgs_blocks(const SgsArgs& a, hipStream_t st) {
+  if (a.hw < 1 || a.hw > kSgsMaxHw || a.num_points < 8 || a.num_points > kSgsMaxPts) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sgs_blocks_kernel, dim3(a.n_chains), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// loss of the proposed bed (+ trend) over the whole grid and the thickness guard, one 256-thread workgroup per chain:
+//   loss = nansum(residual^2 where mc_mask == 1) / (2 sigma^2)      (MCMC.py:1021-1044 on Topography.py:592-600)
+//   bad  = number of cells with guard_mask == 1 and surf - (bed + trend) <= 0   (MCMC.py:1789-1795)
+// S.upd is the guard mask here (grounded_ice_mask); trend may be NULL.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgs_loss_kernel(const StaticFields S, const double* beds, const double* trend, double* loss,
+                                                       int32_t* bad) {
+  __shared__ double red[8];
+  __shared__ int redb[4];
+  const int chain = blockIdx.x, tid = threadIdx.x;
+  const int plane = S.H * S.W;
+  const double* bed = beds + (size_t)chain * plane;
+  auto bed_at = [&](int rr, int cc) { const int q = rr * S.W + cc; return trend ? bed[q] + trend[q] : bed[q]; };
+  double hi = 0.0, lo = 0.0;
+  int nbad = 0;
+  for (int g = tid; g < plane; g += 256) {
+    const int r = g / S.W, c = g - r * S.W;
+    double e = 0.0;
+    if (S.mc[g] == 1) {
+      const double v = cell_residual(S, r, c, bed_at);
+      if (!isnan(v)) e = v * v;
+    }
+    const double s = hi + e, bb = s - hi;
+    lo += (hi - (s - bb)) + (e - bb);
+    hi = s;
+    if (S.upd[g] == 1 && (S.surf[g] - bed_at(r, c)) <= 0.0) ++nbad;
+  }
+  double t = hi + lo;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { t += __shfl_xor(t, off, 64); nbad += __shfl_xor(nbad, off, 64); }
+  if ((tid & 63) == 0) { red[tid >> 6] = t; redb[tid >> 6] = nbad; }
+  __syncthreads();
+  if (tid == 0) {
+    loss[chain] = (((red[0] + red[1]) + red[2]) + red[3]) / S.two_sigma2;
+    bad[chain] = redb[0] + redb[1] + redb[2] + redb[3];
+  }
+}
+
+hipError_t launch_sgs_loss(const StaticFields& S, int n_chains, const double* beds, const double* trend, double* loss, int32_t* bad,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(sgs_loss_kernel, dim3(n_chains), dim3(256), 0, st, S, beds, trend, loss, bad);
+  return hipGetLastError();
+}
+
+// accept[c] != 0: the block of chain c goes from `next` to `cur` and its resampled counts are bumped (MCMC.py:1803-1812);
+// else the block of `next` is restored from `cur`, so that next == cur everywhere again.
+__global__ __launch_bounds__(64) void sgs_commit_kernel(int H, int W, double* cur, double* next, uint32_t* resampled, const int32_t* win,
+                                                        const uint8_t* accept) {
+  const int chain = blockIdx.x;
+  const size_t base = (size_t)chain * H * W;
+  const int r0 = win[4 * chain], r1 = win[4 * chain + 1], c0 = win[4 * chain + 2], c1 = win[4 * chain + 3];
+  const int ww = c1 - c0, n = (r1 - r0) * ww;
+  const bool acc = accept[chain] != 0;
+  for (int p = threadIdx.x; p < n; p += 64) {
+    const size_t q = base + (size_t)(r0 + p / ww) * W + c0 + p % ww;
+    if (acc) { cur[q] = next[q]; resampled[q] += 1u; }
+    else next[q] = cur[q];
+  }
+}
+
+hipError_t launch_sgs_commit(int H, int W, int n_chains, double* cur, double* next, uint32_t* resampled, const int32_t* win,
+                             const uint8_t* accept, hipStream_t st) {
+  hipLaunchKernelGGL(sgs_commit_kernel, dim3(n_chains), dim3(64), 0, st, H, W, cur, next, resampled, win, accept);
+  return hipGetLastError();
+}
+
+}  // namespace gsm

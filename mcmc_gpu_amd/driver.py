@@ -264,3 +264,96 @@ def _gather_results(local, n_chains, lo, hi):
         t = torch.as_tensor(np.stack([np.asarray(r[col], dtype=np.float64) for r in local])).to(dev)
         out_cols.append(parallel.all_gather_chains(t, n_chains).cpu().numpy())
     return [tuple(c[i] for c in out_cols) for i in range(n_chains)]
+
+
+# ---- small-scale chain driver (smallScaleChain_multiprocessing.py:211-399) ---------------------------------------------
+_MSC_FILES = ('loss_mc', 'loss_data', 'loss', 'steps', 'resampled_times', 'blocks_used')
+
+
+def _msc_load_previous(seed_folder):
+    """Resume state of a small-scale seed folder (reference :299-341): the bed_{k}k.txt file names the iteration count."""
+    beds = list(seed_folder.glob('bed_*.txt'))
+    if not beds:
+        return None
+    k = int(beds[0].stem.split('_')[1].replace('k', ''))
+    prev = {key: np.loadtxt(seed_folder / f'{key}_{k}k.txt') for key in _MSC_FILES}
+    return dict(cumulative=k * 1000, bed=np.loadtxt(beds[0]), results=prev,
+                delete=[seed_folder / f'bed_{k}k.txt'] + [seed_folder / f'{key}_{k}k.txt' for key in _MSC_FILES])
+
+
+def _msc_save(seed_folder, result, n_iter, prev):
+    """Text checkpoint files of one finished small-scale segment (reference :363-397)."""
+    seed_folder.mkdir(parents=True, exist_ok=True)
+    beds, loss_mc, loss_data, loss, steps, resampled, blocks = result[:7]
+    cumulative = 0
+    if prev is not None:
+        p = prev['results']
+        loss_mc = np.concatenate([np.atleast_1d(p['loss_mc']), loss_mc])
+        loss_data = np.concatenate([np.atleast_1d(p['loss_data']), loss_data])
+        loss = np.concatenate([np.atleast_1d(p['loss']), loss])
+        steps = np.concatenate([np.atleast_1d(p['steps']), steps])
+        resampled = p['resampled_times'] + resampled
+        blocks = np.vstack([p['blocks_used'], blocks])
+        cumulative = prev['cumulative']
+    cumulative += n_iter
+    label = f'{cumulative // 1000}k'
+    for key, arr in zip(('bed',) + _MSC_FILES, (beds, loss_mc, loss_data, loss, steps, resampled, blocks)):
+        np.savetxt(seed_folder / f'{key}_{label}.txt', arr)
+    if prev is not None:
+        keep = {seed_folder / f'{key}_{label}.txt' for key in ('bed',) + _MSC_FILES}
+        for f in prev['delete']:
+            if f.exists() and f not in keep:
+                f.unlink()
+
+
+def msc_run_wrapper(param_chain, param_run):
+    """Rebuild one small-scale chain from its parameter dict, resume from its seed folder if present, run one segment on
+    the GPU, write the text files, return chain.run's tuple (reference :277-399)."""
+    from . import sgs
+    with contextlib.redirect_stdout(io.StringIO()):
+        chain = sgs.init_msc_chain_by_instance(param_chain)
+    output_path = param_run.get('output_path', './Data/LargeScaleChain/' + str(param_run['lsc_seed'])[:6] + '/SmallScaleChain')
+    seed = param_run['ssc_seed']
+    n_iter = param_run['n_iter']
+    folder = Path(output_path) / f'{str(seed)[:6]}'
+    prev = _msc_load_previous(folder)
+    if prev is not None:
+        chain.initial_bed = prev['bed']
+    chain.chain_id = param_run.get('chain_id', 'Unknown')
+    chain.tqdm_position = param_run.get('tqdm_position', 0)
+    chain.seed = param_run.get('ssc_seed', 'Unkown')
+    result = chain.run(n_iter=n_iter, only_save_last_bed=param_run['only_save_last_bed'], info_per_iter=param_run['info_per_iter'],
+                       plot=param_run['plot'], progress_bar=None if not param_run.get('verbose', False) else param_run['progress_bar'])
+    _msc_save(folder, result, n_iter, prev)
+    return result
+
+
+def smallScaleChain_mp(n_chains, n_workers, smallScaleChain, initial_beds, ssc_rng_seeds, lsc_rng_seed, n_iters,
+                       output_path='./Data/output'):
+    """Run n_chains small-scale chains and return the list of their result tuples (reference :211-274); files under
+    <output_path>/LargeScaleChain/<lsc seed>/SmallScaleChain/<ssc seed>/ as the reference writes them.  Chains that share
+    n_iter run together in one libgsm_hip handle (one workgroup per chain in every launch); `n_workers` is accepted for
+    signature compatibility (the reference's pool size) and not used."""
+    from . import sgs
+    tic = time.time()
+    base = Path(output_path) / 'LargeScaleChain' / str(lsc_rng_seed)[:6] / 'SmallScaleChain'
+    if len(set(int(v) for v in n_iters[:n_chains])) == 1 and n_chains > 0:
+        n_iter = int(n_iters[0])
+        folders = [base / f'{str(ssc_rng_seeds[i])[:6]}' for i in range(n_chains)]
+        prevs = [_msc_load_previous(f) for f in folders]
+        beds = [p['bed'] if p else initial_beds[i] for i, p in enumerate(prevs)]
+        rngs = [np.random.default_rng(seed=ssc_rng_seeds[i]) for i in range(n_chains)]
+        result, _ = sgs.run_many_sgs(smallScaleChain, beds, rngs, n_iter, only_save_last_bed=True, info_per_iter=10, progress_bar=None)
+        for i in range(n_chains):
+            _msc_save(folders[i], result[i], n_iter, prevs[i])
+    else:
+        result = []
+        for i in range(n_chains):
+            cp = deepcopy(smallScaleChain.__dict__)
+            cp['rng_seed'] = ssc_rng_seeds[i]
+            cp['initial_bed'] = initial_beds[i]
+            runp = dict(n_iter=n_iters[i], only_save_last_bed=True, info_per_iter=10, plot=False, progress_bar=False, chain_id=i,
+                        tqdm_position=i + 2, ssc_seed=ssc_rng_seeds[i], lsc_seed=lsc_rng_seed, output_path=str(base))
+            result.append(msc_run_wrapper(cp, runp))
+    print(f'Completed in {time.time() - tic} seconds')
+    return result

@@ -1,0 +1,375 @@
+"""Host-side mirror of the reference's SMALL-scale chain (gstatsMCMC/MCMC.py namespace):
+
+    chain_sgs                      gstatsMCMC/MCMC.py:1445-1911   -> chain_sgs_gpu
+    init_msc_chain_by_instance     gstatsMCMC/MCMC.py:402-431
+    sgs / neighbors / ok_solve     MCMC.py:91-173, gstatsim_custom/neighbors.py:4-64, _krige.py:5-44  -> gsm_sgs_blocks (HIP)
+
+Same class / setter names, argument meaning and return tuple as the reference.  Per iteration the host draws what the
+reference draws from the chain's NumPy generator, in its order (block centre by rejection, block sizes, the shuffle of
+the block's cells, one normal per simulated cell, the accept uniform -- none of which depends on the chain's state) and
+the device does the work: the sequential Gaussian simulation of the block (octant search + ordinary kriging per cell),
+the full-grid mass-conservation loss and thickness guard of the proposed bed, and the commit.  All chains of a call
+share one libgsm_hip handle (run_many_sgs); chain_sgs_gpu.run is the one-chain case.
+
+Normal-score transform (do_transform): the transformer is a caller-supplied object (scikit-learn's QuantileTransformer
+in the reference's drivers).  Its transform / inverse_transform are called on the host once per iteration on the whole
+map, exactly where the reference calls them (MCMC.py:1766, :1777); simulation and loss still run on the device.
+
+Numerics: the kriging systems are solved by pivoted elimination on the device where the reference calls
+numpy.linalg.lstsq, so simulated values agree with the CPU chain to ~1e-9 of the bed's scale, not bit for bit; accept
+decisions are identical unless an accept uniform falls within that distance of its threshold.
+Kept reference behaviour: the loop runs n_iter times and overwrites the record of the initial
+state at index 0.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import sys
+import time
+from copy import deepcopy
+
+import numpy as np
+
+__all__ = ["chain_sgs_gpu", "init_msc_chain_by_instance", "run_many_sgs", "cov_norm", "lag_cov_table"]
+
+
+def cov_norm(h, vtype, sill, nugget, s=None):
+    """Covariance models of gstatsim_custom on normalised lag (covariance.py:4-28), incl. the spherical model's
+    `sill - 1` beyond the range and Matern's h == 0 -> 1e-8 substitution (the input is not mutated here)."""
+    vtype = vtype.lower()
+    if vtype == "exponential":
+        return (sill - nugget) * np.exp(-3 * h)
+    if vtype == "gaussian":
+        return (sill - nugget) * np.exp(-3 * np.square(h))
+    if vtype == "spherical":
+        c = sill - nugget - 1.5 * h + 0.5 * np.power(h, 3)
+        return np.where(h > 1, sill - 1, c)
+    if vtype == "matern":
+        from scipy.special import gamma, kv
+        sc = 0.45246434 * np.exp(-0.70449189 * s) + 1.7863836
+        hh = np.where(h == 0.0, 1e-8, h)
+        c = (sill - nugget) * 2 / gamma(s) * np.power(sc * hh * np.sqrt(s), s) * kv(s, 2 * sc * hh * np.sqrt(s))
+        return np.where(np.isnan(c), sill - nugget, c)
+    raise ValueError("vtype must be Exponential, Gaussian, Spherical or Matern")
+
+
+def rotation_matrix(v: dict) -> np.ndarray:
+    """Anisotropy rotation x scaling (make_rotation_matrix, _krige.py:83-103)."""
+    th = (v["azimuth"] / 180.0) * np.pi
+    return np.dot(np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]),
+                  np.array([[1 / v["major_range"], 0], [0, 1 / v["minor_range"]]]))
+
+
+def lag_cov_table(vario: dict, hw: int, dx: float, dy: float) -> np.ndarray:
+    """Covariance at every integer lag (di, dj), |di|, |dj| <= 2 hw, between two cells of an axis-aligned grid with column
+    spacing dx and row spacing dy (signed): what make_sigma / make_rho (_krige.py:105-143) evaluate pair by pair."""
+    m = 2 * int(hw)
+    R = rotation_matrix(vario)
+    di = np.arange(-m, m + 1)[:, None] * dy
+    dj = np.arange(-m, m + 1)[None, :] * dx
+    m0 = dj * R[0, 0] + di * R[1, 0]
+    m1 = dj * R[0, 1] + di * R[1, 1]
+    h = np.sqrt(m0 * m0 + m1 * m1)
+    return np.ascontiguousarray(cov_norm(h, vario["vtype"], vario["sill"], vario["nugget"], vario.get("s")))
+
+
+def _axes(xx, yy):
+    xs, ys = np.ascontiguousarray(xx[0, :], dtype=np.float64), np.ascontiguousarray(yy[:, 0], dtype=np.float64)
+    if not (np.array_equal(xx, np.broadcast_to(xs[None, :], xx.shape)) and np.array_equal(yy, np.broadcast_to(ys[:, None], yy.shape))):
+        raise NotImplementedError("the device SGS needs an axis-aligned grid (xx[i, j] = x[j], yy[i, j] = y[i])")
+    dx, dy = xs[1] - xs[0], ys[1] - ys[0]
+    if not (np.allclose(np.diff(xs), dx, rtol=1e-9, atol=0) and np.allclose(np.diff(ys), dy, rtol=1e-9, atol=0)):
+        raise NotImplementedError("the device SGS needs uniform grid spacing")
+    return xs, ys, float(dx), float(dy)
+
+
+class chain_sgs_gpu:
+    """Small-scale (SGS block) Metropolis chain executed on the MI355X (reference chain_sgs, MCMC.py:1445-1911)."""
+
+    def __init__(self, xx, yy, initial_bed, surf, velx, vely, dhdt, smb, cond_bed, data_mask, grounded_ice_mask, resolution):
+        self.xx, self.yy = xx, yy
+        self.initial_bed = initial_bed
+        self.surf, self.velx, self.vely, self.dhdt, self.smb = surf, velx, vely, dhdt, smb
+        self.cond_bed = cond_bed
+        self.data_mask = data_mask
+        self.grounded_ice_mask = grounded_ice_mask
+        self.resolution = resolution
+        self.loss_function_list = []
+        self.sample_loc = None
+        shp = initial_bed.shape
+        if any(a.shape != shp for a in (surf, velx, vely, dhdt, smb, cond_bed, data_mask)):
+            raise Exception('the shape of bed, surf, velx, vely, dhdt, smb, radar_bed, data_mask need to be same')
+        self.do_transform = False
+        self.nst_trans = None
+        self.trend = None
+        self.detrend_map = False
+
+    # ---- setters shared with the large-scale chain (MCMC.py:849-872, :950-1018) ---------------------------------------
+    def set_update_region(self, update_in_region, region_mask=[]):
+        self.update_in_region = update_in_region
+        if update_in_region is False:
+            self.region_mask = np.full(self.xx.shape, 1)
+        else:
+            if np.shape(region_mask) != self.xx.shape:
+                raise ValueError('the region_mask input is invalid. It has to be a 2D numpy array with the shape of the map')
+            self.region_mask = region_mask
+
+    def set_loss_type(self, sigma_mc=-1, massConvInRegion=True):
+        self.mc_region_mask = self.region_mask if massConvInRegion else np.full(self.xx.shape, 1)
+        self.sigma_mc = sigma_mc
+
+    def set_sample_points_locations(self, loc):
+        self.sample_loc = loc
+
+    # ---- chain_sgs setters (MCMC.py:1466-1598) ------------------------------------------------------------------------
+    def set_normal_transformation(self, nst_trans, do_transform=True):
+        self.do_transform = do_transform
+        self.nst_trans = nst_trans if do_transform else None
+
+    def set_trend(self, trend=None, detrend_map=True):
+        if detrend_map == True:  # noqa: E712
+            if trend is None or len(trend) != len(self.xx) or trend.shape != self.xx.shape:
+                raise ValueError('if detrend_map is set to True, then the trend of the topography, which is a 2D numpy array, must be provided')
+            self.trend = trend
+        else:
+            self.trend = None
+        self.detrend_map = detrend_map
+
+    def set_variogram(self, vario_type, vario_range, vario_sill, vario_nugget, isotropic=True, vario_smoothness=None,
+                      vario_azimuth=None):
+        if vario_type in ('Gaussian', 'Exponential', 'Spherical'):
+            pass
+        elif vario_type == 'Matern':
+            if (vario_smoothness is None) or (vario_smoothness <= 0):
+                raise ValueError('vario_smoothness argument should be a positive float when the vario_type is Matern')
+        else:
+            raise ValueError('vario_type argument should be one of the following: Gaussian, Exponential, Spherical, or Matern')
+        self.vario_type = vario_type
+        if isotropic:
+            self.vario_param = [0, vario_nugget, vario_range, vario_range, vario_sill, vario_type, vario_smoothness]
+        else:
+            if len(vario_range) != 2:
+                raise ValueError("vario_range need to be a list with two floats to specifying for major range and minor range of the variogram when isotropic is set to False")
+            self.vario_param = [vario_azimuth, vario_nugget, vario_range[0], vario_range[1], vario_sill, vario_type, vario_smoothness]
+
+    def set_sgs_param(self, sgs_num_nearest_neighbors, sgs_searching_radius, sgs_rand_dropout_on=False, dropout_rate=0):
+        if sgs_rand_dropout_on == False:  # noqa: E712
+            dropout_rate = 0
+        self.sgs_param = [sgs_num_nearest_neighbors, sgs_searching_radius, sgs_rand_dropout_on, dropout_rate]
+
+    def set_block_sizes(self, block_min_x, block_max_x, block_min_y, block_max_y):
+        self.block_min_x, self.block_min_y = block_min_x, block_min_y
+        self.block_max_x, self.block_max_y = block_max_x, block_max_y
+
+    def set_random_generator(self, rng_seed=None):
+        if rng_seed is None:
+            rng = np.random.default_rng()
+        elif isinstance(rng_seed, (int, np.integer)):
+            rng = np.random.default_rng(seed=int(rng_seed))
+            self.rng_seed = int(rng_seed)
+        elif isinstance(rng_seed, np.random.Generator):
+            rng = rng_seed
+        else:
+            raise ValueError('Seed should be an integer, a NumPy random Generator, or None')
+        self.rng = rng
+
+    def loss(self, massConvResidual, dataDiff):
+        loss_mc = np.nansum(np.square(massConvResidual[self.mc_region_mask == 1])) / (2 * self.sigma_mc ** 2)
+        return loss_mc + 0, loss_mc, 0
+
+    def _vario(self):
+        vp = self.vario_param
+        v = dict(azimuth=vp[0], nugget=vp[1], major_range=vp[2], minor_range=vp[3], sill=vp[4], vtype=vp[5])
+        if vp[5] == 'Matern':
+            v['s'] = vp[6]
+        return v
+
+    # ---- host draws of one iteration (MCMC.py:1747-1760, sgs :128, :165, run :1799) -------------------------------------
+    def _draw_iteration(self, rng, cond_is_data):
+        H, W = self.xx.shape
+        while True:
+            ix = rng.integers(low=0, high=H, size=1)[0]
+            iy = rng.integers(low=0, high=W, size=1)[0]
+            if self.region_mask[ix, iy] == 1:
+                break
+        bsx = rng.integers(low=self.block_min_x, high=self.block_max_x, size=1)[0]
+        bsy = rng.integers(low=self.block_min_y, high=self.block_max_y, size=1)[0]
+        r0 = max(0, int(ix - bsx / 2)); r1 = min(H, int(ix + bsx / 2))
+        c0 = max(0, int(iy - bsy / 2)); c1 = min(W, int(iy + bsy / 2))
+        ii, jj = np.meshgrid(np.arange(r0, r1), np.arange(c0, c1), indexing='ij')
+        inds = np.array([ii.flatten(), jj.flatten()]).T
+        rng.shuffle(inds)
+        need = ~cond_is_data[inds[:, 0], inds[:, 1]] if inds.shape[0] else np.zeros(0, bool)
+        z = np.zeros(inds.shape[0])
+        if need.any():
+            z[need] = rng.standard_normal(int(need.sum()))     # rng.normal(est, sd, 1) = est + sd * standard normal
+        u = rng.random()
+        return (ix, iy, bsx, bsy), (r0, r1, c0, c1), inds.astype(np.int32), z, u
+
+    def run(self, n_iter, only_save_last_bed=False, info_per_iter=100, plot=True, progress_bar=True):
+        """n_iter SGS-block Metropolis iterations from self.initial_bed; returns the reference's tuple (bed or bed_cache,
+        loss_mc_cache, loss_data_cache, loss_cache, step_cache, resampled_times, blocks_cache[, sample_values])."""
+        if not hasattr(self, 'rng'):
+            self.set_random_generator(getattr(self, 'rng_seed', None))
+        out, _ = run_many_sgs(self, [self.initial_bed], [self.rng], n_iter, only_save_last_bed=only_save_last_bed,
+                              info_per_iter=info_per_iter, progress_bar=progress_bar)
+        return out[0]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, info_per_iter=100, progress_bar=None, device=None):
+    """n small-scale chains of one template (same static fields, variogram, block sizes) in ONE handle.  rngs: one NumPy
+    Generator per chain (consumed exactly as chain_sgs.run consumes chain.rng).  Returns (list of result tuples, rngs)."""
+    import torch
+    from .engine import GsmEngine
+    H, W = chain.xx.shape
+    n = len(initial_beds)
+    if len(rngs) != n:
+        raise ValueError('need one random generator per chain')
+    n_iter = int(n_iter)
+    xs, ys, dx, dy = _axes(np.asarray(chain.xx, dtype=np.float64), np.asarray(chain.yy, dtype=np.float64))
+    rad, npts = float(chain.sgs_param[1]), int(chain.sgs_param[0])
+    hw = int(math.ceil(rad / abs(dx)))
+    vario = chain._vario()
+    detrend = bool(chain.detrend_map)
+    trend = np.asarray(chain.trend, dtype=np.float64) if detrend else None
+    nst = chain.nst_trans if chain.do_transform else None
+    cond_c = np.asarray(chain.cond_bed, dtype=np.float64) - trend if detrend else np.asarray(chain.cond_bed, dtype=np.float64).copy()
+    z_cond = nst.transform(cond_c.reshape(-1, 1)).reshape(H, W) if nst is not None else cond_c
+    cond_is_data = ~np.isnan(z_cond)
+    track = chain.sample_loc is not None
+    keep_all = not only_save_last_bed
+
+    eng = GsmEngine(H, W, n, device)
+    try:
+        dev = eng.dev
+        eng.set_static(chain.surf, chain.velx, chain.vely, chain.dhdt, chain.smb, None, chain.grounded_ice_mask,
+                       chain.mc_region_mask, chain.resolution, chain.sigma_mc)
+        f64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        d_xs, d_ys = f64(xs), f64(ys)
+        d_lag = f64(lag_cov_table(vario, hw, dx, dy))
+        d_zcond = f64(z_cond)
+        d_trend = f64(trend) if detrend else None
+        bed_c = np.stack([np.asarray(b, dtype=np.float64) - trend if detrend else np.asarray(b, dtype=np.float64) for b in initial_beds])
+        cur = f64(bed_c)
+        nxt = cur.clone()
+        resampled = torch.zeros((n, H, W), dtype=torch.int32, device=dev)
+        d_loss = torch.empty(n, dtype=torch.float64, device=dev)
+        d_bad = torch.empty(n, dtype=torch.int32, device=dev)
+        lib, h = eng.lib, eng.h
+
+        def loss_of(t):
+            eng._check(lib.gsm_sgs_loss(h, _ptr(t), _ptr(d_trend), _ptr(d_loss), _ptr(d_bad), eng._stream()))
+            return d_loss.cpu().numpy().copy(), d_bad.cpu().numpy().copy()
+
+        loss_prev, _ = loss_of(cur)
+        loss_cache = np.zeros((n, n_iter)); step_cache = np.zeros((n, n_iter)); blocks_cache = np.full((n, n_iter, 4), np.nan)
+        loss_cache[:, 0] = loss_prev
+        if keep_all:
+            bed_cache = np.zeros((n, n_iter, H, W))
+            bed_cache[:, 0] = bed_c
+        if track:
+            loc = np.asarray(chain.sample_loc)
+            ij = np.zeros(loc.shape, dtype=np.int64)
+            for k in range(loc.shape[0]):
+                i_, j_ = np.where((chain.xx == loc[k, 0]) & (chain.yy == loc[k, 1]))
+                ij[k] = [int(i_[0]), int(j_[0])]
+            sample_values = np.zeros((n, ij.shape[0], n_iter))
+            for c in range(n):
+                sample_values[c, :, 0] = np.asarray(initial_beds[c])[ij[:, 0], ij[:, 1]]
+        t0 = time.time()
+        for it in range(n_iter):
+            wins = np.empty((n, 4), np.int32); offs = np.zeros(n + 1, np.int32); us = np.empty(n)
+            cells, zs = [], []
+            for c in range(n):
+                blk, win, inds, z, us[c] = chain._draw_iteration(rngs[c], cond_is_data)
+                blocks_cache[c, it] = blk
+                wins[c] = win
+                cells.append(inds); zs.append(z)
+                offs[c + 1] = offs[c] + inds.shape[0]
+            d_win = torch.as_tensor(wins).to(dev)
+            d_off = torch.as_tensor(offs).to(dev)
+            d_cells = torch.as_tensor(np.ascontiguousarray(np.concatenate(cells) if offs[-1] else np.zeros((1, 2), np.int32))).to(dev)
+            d_z = torch.as_tensor(np.concatenate(zs) if offs[-1] else np.zeros(1)).to(dev)
+            if nst is not None:
+                # the caller's transformer on the whole map, where the reference calls it (MCMC.py:1766)
+                nxt.copy_(f64(np.stack([nst.transform(bed_c[c].reshape(-1, 1)).reshape(H, W) for c in range(n)])))
+            with torch.cuda.device(dev):
+                eng._check(lib.gsm_sgs_blocks(h, _ptr(nxt), _ptr(d_zcond), _ptr(d_win), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), hw,
+                                              rad, npts, float(vario["sill"]), _ptr(d_off), _ptr(d_cells), _ptr(d_z), None, eng._stream()))
+            if nst is not None:
+                newsim = nxt.cpu().numpy()
+                bed_next = np.stack([nst.inverse_transform(newsim[c].reshape(-1, 1)).reshape(H, W) for c in range(n)])   # MCMC.py:1777
+                d_next = f64(bed_next)
+                loss_next, bad = loss_of(d_next)
+            else:
+                loss_next, bad = loss_of(nxt)
+            loss_next = np.where(bad > 0, np.inf, loss_next)
+            with np.errstate(over='ignore', invalid='ignore'):
+                p_acc = np.where(loss_prev > loss_next, 1.0, np.minimum(1.0, np.exp(loss_prev - loss_next)))
+            acc = us <= p_acc
+            d_acc = torch.as_tensor(acc.astype(np.uint8)).to(dev)
+            if nst is not None:
+                for c in np.flatnonzero(acc):
+                    bed_c[c] = bed_next[c]
+                    r0, r1, c0, c1 = wins[c]
+                    resampled[c, r0:r1, c0:c1] += 1
+            else:
+                with torch.cuda.device(dev):
+                    eng._check(lib.gsm_sgs_commit(h, _ptr(cur), _ptr(nxt), _ptr(resampled), _ptr(d_win), _ptr(d_acc), eng._stream()))
+            loss_prev = np.where(acc, loss_next, loss_prev)
+            loss_cache[:, it] = loss_prev
+            step_cache[:, it] = acc
+            if keep_all or track:
+                if nst is None:
+                    bed_c = cur.cpu().numpy()
+                if keep_all:
+                    bed_cache[:, it] = bed_c + trend if detrend else bed_c
+                if track:
+                    for c in range(n):
+                        sample_values[c, :, it] = bed_c[c][ij[:, 0], ij[:, 1]]
+            if progress_bar is not None and (it % max(int(info_per_iter), 1) == 0 or it == n_iter - 1):
+                el = time.time() - t0
+                print(f"Chain {getattr(chain, 'chain_id', 0)} ({str(getattr(chain, 'seed', 'Unknown'))[:6]}): "
+                      f"{100 * it / max(n_iter - 1, 1):3.0f}% | it/s: {(it + 1) / max(el, 1e-9):7.2f} | n: {n_iter} | "
+                      f"loss: {loss_cache[0, it]:.3e} | acc: {step_cache[0, :it + 1].sum() / (it + 1):.4f}", file=sys.stdout, flush=True)
+        if nst is None:
+            bed_c = cur.cpu().numpy()
+        res = resampled.cpu().numpy().astype(np.float64)
+    finally:
+        eng.close()
+    out = []
+    for c in range(n):
+        last = bed_c[c] + trend if detrend else bed_c[c]
+        tup = (bed_cache[c] if keep_all else last, loss_cache[c].copy(), np.zeros(n_iter), loss_cache[c], step_cache[c], res[c],
+               blocks_cache[c])
+        out.append(tup + (sample_values[c],) if track else tup)
+    return out, rngs
+
+
+def init_msc_chain_by_instance(param_dict):
+    """Rebuild a small-scale chain from a copy of another one's __dict__ (+ 'rng_seed', 'initial_bed') (MCMC.py:402-431)."""
+    p = param_dict
+    ch = chain_sgs_gpu(p['xx'], p['yy'], p['initial_bed'], p['surf'], p['velx'], p['vely'], p['dhdt'], p['smb'], p['cond_bed'],
+                       p['data_mask'], p['grounded_ice_mask'], p['resolution'])
+    ch.update_in_region = p['update_in_region']
+    ch.region_mask = p['region_mask']
+    ch.sigma_mc = p['sigma_mc']
+    ch.mc_region_mask = p['mc_region_mask']
+    ch.block_min_x, ch.block_min_y = p['block_min_x'], p['block_min_y']
+    ch.block_max_x, ch.block_max_y = p['block_max_x'], p['block_max_y']
+    ch.do_transform = p['do_transform']
+    ch.nst_trans = deepcopy(p['nst_trans'])
+    ch.trend = p['trend']
+    ch.detrend_map = p['detrend_map']
+    ch.vario_type = p['vario_type']
+    ch.vario_param = deepcopy(p['vario_param'])
+    ch.sgs_param = deepcopy(p['sgs_param'])
+    ch.rng = np.random.default_rng(seed=p['rng_seed'])
+    ch.rng_seed = p['rng_seed']
+    ch.sample_loc = deepcopy(p['sample_loc'])
+    return ch

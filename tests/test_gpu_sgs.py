@@ -1,0 +1,113 @@
+"""-m gpu: the small-scale chain on the device against the reference through golden F10 and the oracle.
+
+Tolerance.  The device solves every ordinary-kriging system by pivoted elimination, the reference by numpy.linalg.lstsq
+(SVD): kriging estimates agree to ~1e-10 relative and the simulated beds, which feed on each other cell after cell, to
+1e-7 m on beds of order 1e3 m (asserted: 1e-7 absolute); losses to 1e-9 relative.  Accept masks, blocks and resampled
+counts must be identical.  Both F10 variants: (a) exponential variogram, no transform / trend; (b) Matern variogram,
+detrended, normal-score transform (the caller's scikit-learn object, called on the host as the reference does)."""
+import json
+
+import numpy as np
+import pytest
+
+import sgs_common as sc
+import sgs_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sgs_one_block_equals_oracle_trace():
+    """gsm_sgs_blocks alone on the first block of F10a: neighbour counts exact, estimates / variances to 1e-9 relative."""
+    import ctypes as C
+    import torch
+    from mcmc_gpu_amd import sgs
+    from mcmc_gpu_amd.engine import GsmEngine, _ptr
+    g, prob, cfg, ch = sc.setup("a")
+    H = int(g["H"])
+    rng = np.random.default_rng(seed=int(g["a_seed"]))
+    trace = []
+    so.run_chain_sgs(cfg, prob["bed"], 1, rng, trace=trace)           # the oracle's first iteration
+    is_data = ~np.isnan(prob["cond_bed"])
+    blk, win, inds, z, u = ch._draw_iteration(np.random.default_rng(seed=int(g["a_seed"])), is_data)
+    eng = GsmEngine(H, H, 1)
+    dev = eng.dev
+    f64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+    xs, ys, dx, dy = sgs._axes(prob["xx"], prob["yy"])
+    hw = int(np.ceil(float(g["radius"]) / abs(dx)))
+    vario = ch._vario()
+    grid = f64(prob["bed"][None])
+    tr = torch.zeros((inds.shape[0], 3), dtype=torch.float64, device=dev)
+    d = dict(zc=f64(prob["cond_bed"]), win=torch.as_tensor(np.array([win], np.int32)).to(dev), xs=f64(xs), ys=f64(ys),
+             lag=f64(sgs.lag_cov_table(vario, hw, dx, dy)), off=torch.as_tensor(np.array([0, inds.shape[0]], np.int32)).to(dev),
+             cells=torch.as_tensor(inds).to(dev), z=f64(z))
+    eng._check(eng.lib.gsm_sgs_blocks(eng.h, _ptr(grid), _ptr(d["zc"]), _ptr(d["win"]), _ptr(d["xs"]), _ptr(d["ys"]), _ptr(d["lag"]),
+                                      hw, float(g["radius"]), int(g["num_points"]), float(vario["sill"]), _ptr(d["off"]),
+                                      _ptr(d["cells"]), _ptr(d["z"]), _ptr(tr), eng._stream()))
+    t = tr.cpu().numpy()
+    sim = t[t[:, 0] >= 0]
+    exp = np.array(trace)
+    assert sim.shape[0] == exp.shape[0] > 0
+    assert np.array_equal(sim[:, 0], exp[:, 2])                       # neighbour counts
+    np.testing.assert_allclose(sim[:, 1], exp[:, 3], rtol=1e-9)       # kriging estimates
+    np.testing.assert_allclose(sim[:, 2], exp[:, 4], rtol=1e-7, atol=1e-9 * float(vario["sill"]))
+    # cells outside the block untouched, data cells of the block keep their value
+    out = grid[0].cpu().numpy()
+    r0, r1, c0, c1 = win
+    mask = np.ones((H, H), bool); mask[r0:r1, c0:c1] = False
+    assert np.array_equal(out[mask], prob["bed"][mask])
+    blockd = is_data[r0:r1, c0:c1]
+    assert np.array_equal(out[r0:r1, c0:c1][blockd], prob["cond_bed"][r0:r1, c0:c1][blockd])
+    assert not np.isnan(out).any()
+    eng.close()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_chain_sgs_gpu_equals_reference_fixture(tag):
+    g, prob, cfg, ch = sc.setup(tag)
+    n_iter = int(g["n_iter"])
+    out = ch.run(n_iter, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None)
+    assert len(out) == 7
+    assert np.array_equal(out[4], g[f"{tag}_steps"]), "accept mask differs from the reference"
+    assert np.array_equal(out[6], g[f"{tag}_blocks"])
+    assert np.array_equal(out[5], g[f"{tag}_resampled"])
+    np.testing.assert_allclose(out[3], g[f"{tag}_loss"], rtol=1e-9)
+    np.testing.assert_allclose(out[0], g[f"{tag}_bed"], rtol=0, atol=1e-7)
+    assert np.array_equal(out[1], out[3]) and not out[2].any()
+    assert ch.rng.bit_generator.state == json.loads(str(g[f"{tag}_rng_state"]))
+    assert out[4].sum() >= 2
+
+
+def test_small_scale_driver_runs_config0_literally(tmp_path):
+    """BASELINE configs[0]: smallScaleChain, 64x64 grid, 4 chains, through the smallScaleChain_mp counterpart; all four
+    chains in one handle == each chain alone through msc_run_wrapper (text files included), and a second segment resumes."""
+    from copy import deepcopy
+    from mcmc_gpu_amd import driver, sgs
+    prob = sc.problem(64)
+    ch = sgs.chain_sgs_gpu(prob["xx"], prob["yy"], prob["bed"], prob["surf"], prob["velx"], prob["vely"], prob["dhdt"], prob["smb"],
+                           prob["cond_bed"], prob["data_mask"], np.ones((64, 64), dtype=int), prob["resolution"])
+    ch.set_update_region(True, prob["region_mask"])
+    ch.set_loss_type(sigma_mc=60.0, massConvInRegion=True)
+    ch.set_normal_transformation(None, do_transform=False)
+    ch.set_trend(None, detrend_map=False)
+    ch.set_variogram("Exponential", 6000.0, float(np.var(prob["bed"])), 0.0, isotropic=True)
+    ch.set_sgs_param(16, 4000.0)
+    ch.set_block_sizes(3, 8, 3, 8)
+    seeds = [901, 902, 903, 904]
+    beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(4)]
+    res = driver.smallScaleChain_mp(4, 3, ch, beds, seeds, 123456789, [1000] * 4, output_path=str(tmp_path / "all"))
+    base = tmp_path / "all" / "LargeScaleChain" / "123456" / "SmallScaleChain"
+    names = sorted(p.name for p in (base / "902").iterdir())
+    assert names == sorted(f"{k}_1k.txt" for k in ("bed", "loss_mc", "loss_data", "loss", "steps", "resampled_times", "blocks_used"))
+    cp = deepcopy(ch.__dict__); cp["rng_seed"] = 902; cp["initial_bed"] = beds[1]
+    alone = driver.msc_run_wrapper(cp, dict(n_iter=1000, only_save_last_bed=True, info_per_iter=10, plot=False, progress_bar=False,
+                                            chain_id=1, tqdm_position=3, ssc_seed=902, lsc_seed=123456789,
+                                            output_path=str(tmp_path / "alone")))
+    for a, b in zip(res[1], alone):
+        assert np.array_equal(a, b, equal_nan=True)                   # same device arithmetic: bit-equal
+    assert np.array_equal(np.loadtxt(base / "902" / "bed_1k.txt"), np.loadtxt(tmp_path / "alone" / "902" / "bed_1k.txt"))
+    assert 0.05 < np.mean([r[4].mean() for r in res]) < 0.95
+    # second segment resumes from the text files
+    driver.smallScaleChain_mp(4, 3, ch, beds, seeds, 123456789, [1000] * 4, output_path=str(tmp_path / "all"))
+    assert sorted(p.name for p in (base / "903").iterdir()) == sorted(
+        f"{k}_2k.txt" for k in ("bed", "loss_mc", "loss_data", "loss", "steps", "resampled_times", "blocks_used"))
+    assert np.loadtxt(base / "903" / "loss_2k.txt").shape == (2000,)
