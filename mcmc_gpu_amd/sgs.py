@@ -205,7 +205,7 @@ class chain_sgs_gpu:
         if need.any():
             z[need] = rng.standard_normal(int(need.sum()))     # rng.normal(est, sd, 1) = est + sd * standard normal
         u = rng.random()
-        return (ix, iy, bsx, bsy), (r0, r1, c0, c1), inds.astype(np.int32), z, u
+        return (ix, iy, bsx, bsy), (r0, r1, c0, c1), np.ascontiguousarray(inds, dtype=np.int32), z, u
 
     def run(self, n_iter, only_save_last_bed=False, info_per_iter=100, plot=True, progress_bar=True):
         """n_iter SGS-block Metropolis iterations from self.initial_bed; returns the reference's tuple (bed or bed_cache,
