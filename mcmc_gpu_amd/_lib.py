@@ -74,6 +74,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         if not force and not is_version and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_t):
             continue
         diag = ["-DGSM_STAMPS"] if os.environ.get("GSM_STAMPS") else []
+        if os.environ.get("GSM_STAMP_TID"):
+            diag.append("-DGSM_STAMP_TID=" + os.environ["GSM_STAMP_TID"])
         if is_version:
             diag.append(f'-DGSM_SRC_HASH="{src_hash}"')
         cmd = [hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(s, []), *diag, "-c", "-o", str(obj), str(src)]

@@ -5,23 +5,31 @@
 // Only the chain state touches HBM: read bed (window + halo) and carried energy (window); on accept write both back
 // and bump resampled_times -- the algorithmic traffic of SURVEY.md section 8d plus the halo ring.
 //
+// Wave roles.  On gfx950 the fp64 matrix pipe and the fp64 vector pipe have the same peak rate and run side by side, but a
+// workgroup that walks through the proposal phase by phase uses them one after the other.  The proposal of step s + 1 does
+// not depend on the chain's state (counter-based draws), so the workgroup is split for the two matrix-core stages:
+//   waves 4..15 (3 per SIMD)  the inverse-DFT stages of step s on the matrix cores (operands from LDS)
+//   waves 0..3  (1 per SIMD)  Philox + Box-Muller + spectral amplitude of step s + 1 on the vector pipe; the folded
+//                             coefficients go to a per-chain 68 KiB scratch in global memory (L2 resident).  They are the
+//                             oldest wave of their SIMD and raise their priority: VALU issue goes to them first
+// and the scratch is copied into the LDS coefficient planes by LDS-DMA (no registers) once the flux tiles that overlay
+// them are dead (after phase D of step s), flying under the reduction / commit phases.  Every other phase uses all 16 waves.
+//
 // Per step:
 //   P0  issue the loads of the bed / energy of the window into registers (HBM latency runs under the proposal)
-//   P   proposal: Philox + Box-Muller coefficients -> LDS planes, two fp64 MFMA DFT stages, standardise,
-//       scale x edge mask -> LDS field tile
-//   A   candidate bed = bed + f * weight (where update_mask), thickness guard, fluxes -> two LDS tiles (they overlay
-//       the proposal's planes), sum of the carried energy
-//   D   5-point stencil on the flux tiles -> new energies;  R  reduction + accept test;  E  commit on accept
+//   S1  stage 1 of the inverse DFT (12 waves)  ||  coefficients of step s+1, first two thirds (4 waves)
+//   S2  stage 2 (one output tile per wave)      ||  coefficients of step s+1, rest (4 waves, before their tile if any)
+//   std standardise, scale x edge mask -> LDS field tile
+//   A   candidate bed = bed + f * weight (where update_mask), thickness guard, fluxes -> two LDS tiles (they overlay the
+//       proposal's planes), sum of the carried energy
+//   D   5-point stencil on the flux tiles -> new energies;  R  reduction + accept test;  then the LDS-DMA of the next
+//       step's coefficient planes and DFT tables is issued;  E  commit on accept
 // LDS (80 x 80 blocks): flux tiles / DFT planes 105 KiB + field tile 50 KiB + scratch < 160 KiB.
 //
 // The arithmetic of a step is the same, operation for operation, as gsm_propose_philox followed by gsm_run_replay
 // (tests/test_gpu_philox.py: bit-identical losses, accepts and beds).
 #include "gsm_internal.h"
 #include "device_util.h"
-#ifdef GSM_STAMPS
-// absolute stamps of the proposal's internal phases go to LDS behind its reduction scratch; the kernel folds them in
-#define PSTAMP(slot) do { if (threadIdx.x == 0) ((unsigned long long*)(red + 32))[slot] = __builtin_amdgcn_s_memtime(); } while (0)
-#endif
 #include "proposal_device.h"
 #include <math.h>
 #include <stdlib.h>
@@ -32,10 +40,19 @@ namespace gsm {
 
 using namespace dev;
 
+constexpr int kNWC = 8;                  // coefficient waves: waves 0..7, the two OLDEST waves of each SIMD (VALU issue is arbitrated
+                                         // by priority, then age: MI355X_MICROARCH.md, 'Two waves per SIMD')
+constexpr int kNWM = kNW - kNWC;         // matrix-core waves of stage 1: waves 4..15
+constexpr int kNTV = kNWC * 64;          // threads of the coefficient waves
+constexpr int kUPW = 3;                   // stage-1 units per matrix-core wave (24 units = 12 output tiles)
+
 #ifdef GSM_STAMPS
 // diagnostic build only (GSM_STAMPS=1 at build time): per-workgroup cycle totals of the phases, thread 0
 __device__ unsigned long long g_stamps_fused[4096 * 16];
-#define STAMP(slot) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+#ifndef GSM_STAMP_TID
+#define GSM_STAMP_TID 512    // first lane of the first matrix-core wave; 0: first coefficient wave
+#endif
+#define STAMP(slot) do { if (tid == GSM_STAMP_TID) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
     st_acc[slot] += t_ - st_last; st_last = t_; } } while (0)
 #else
 #define STAMP(slot) do {} while (0)
@@ -50,54 +67,86 @@ size_t fused_lds_doubles(const FusedArgs& a) {
   return (size_t)fused_work_len(a) + (size_t)fused_fld_len(a) + 4 * kNW + 32 + 16;
 }
 
-static_assert(sizeof(PropScalars) == 104, "PropScalars layout is unpacked dword by dword below");
+static_assert(sizeof(PropScalars) == 104, "PropScalars: 104-byte records, read field by field with scalar loads");
 
-// per-step scalars of the proposal: lanes 0..25 each load one dword of the record (one VGPR in flight for a whole
-// step), the fields are then broadcast to SGPRs with v_readlane
-__device__ __forceinline__ PropScalars unpack_scalars(uint32_t dw_lane) {
-  auto dw = [&](int i) { return (uint32_t)__builtin_amdgcn_readlane((int)dw_lane, i); };
-  auto f64 = [&](int i) { return __builtin_bit_cast(double, ((uint64_t)dw(2 * i + 1) << 32) | dw(2 * i)); };
-  PropScalars r;
-  r.scale = f64(0); r.nug = f64(1); r.range_x = f64(2); r.range_y = f64(3); r.u = f64(4);
-  r.aa = f64(5); r.m_const = f64(6); r.m_kappa = f64(7);
-  r.si = (int)dw(16); r.row = (int)dw(17); r.col = (int)dw(18); r.bh = (int)dw(19);
-  r.bw = (int)dw(20); r.fy_off = (int)dw(21); r.g_off = (int)dw(22); r.pad = 0;
-  r.mask_off = (int64_t)(((uint64_t)dw(25) << 32) | dw(24));
-  return r;
+// The per-step record (propose_scalars_kernel's output) is read through the constant address space: the address is uniform
+// and the memory is never written by this kernel, so every access is a scalar load.  Each phase re-reads the few fields it
+// needs through a laundered pointer instead of keeping the whole record (and everything derived from it) in SGPRs for the
+// whole step -- the kernel has far more uniform values than scalar registers, and a spilled SGPR comes back through
+// v_readlane, a VECTOR instruction (round 1: ~8 % of the vector instructions of a step were such reloads).
+typedef const __attribute__((address_space(4))) PropScalars* crec_t;
+
+// copy of a struct that lives in the constant address space (device pass only: the host pass never runs this code)
+template <class T>
+__device__ __forceinline__ T load_c(const __attribute__((address_space(4))) T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *p;
+#else
+  (void)p;
+  return T();
+#endif
+}
+
+// window of a step, clipped to the grid (MCMC.py:1266-1276), its halo (MCMC.py:1293-1297) and the matching sub-block of f
+struct Win {
+  int r0, r1, c0, c1;      // window rows / cols [r0, r1) x [c0, c1)
+  int mr0, mc0;            // first row / col of the block that lies inside the grid
+  int wh, ww;              // window size
+  int hr0, hc0, hr1, hc1;  // halo tile
+  int tw, ncell;           // tile width, tile cells
+  int dr, dc;              // window origin inside the tile (0 or 1)
+  uint32_t m_tw;           // magic reciprocal of tw
+};
+__device__ __forceinline__ Win make_win(int H, int W, int row, int col, int bh, int bw) {
+  Win g;
+  g.r0 = max(0, row - bh / 2); g.r1 = min(H, row + bh / 2);
+  g.c0 = max(0, col - bw / 2); g.c1 = min(W, col + bw / 2);
+  g.mr0 = max(bh - g.r1, 0); g.mc0 = max(bw - g.c1, 0);
+  g.wh = g.r1 - g.r0; g.ww = g.c1 - g.c0;
+  g.hr0 = max(0, g.r0 - 1); g.hr1 = min(H, g.r1 + 1);
+  g.hc0 = max(0, g.c0 - 1); g.hc1 = min(W, g.c1 + 1);
+  g.tw = g.hc1 - g.hc0;
+  g.ncell = (g.hr1 - g.hr0) * g.tw;
+  g.m_tw = magic_for((uint32_t)g.tw);
+  g.dr = g.r0 - g.hr0; g.dc = g.c0 - g.hc0;
+  return g;
 }
 
 template <typename TS, int KT, bool FAST_DIV>
 __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa) {
   constexpr bool F32 = sizeof(TS) == 4;
-  const StepArgs& a = fa.T;
-  const ProposeArgs& pa = fa.P;
+  // The kernel arguments are re-read from the kernarg segment (scalar loads, scalar cache) in every phase through a
+  // laundered pointer: read once, they would be loop invariants that the compiler keeps in -- and spills from -- SGPRs.
+  typedef const __attribute__((address_space(4))) FusedArgs* cargs_t;
+  auto kargs = [] { cargs_t p = (cargs_t)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p)); return p; };
   extern __shared__ double lds[];
-  const int work_len = fa.work_len;
   double* __restrict__ qx = lds;
-  double* __restrict__ qy = lds + a.tile_cap;
-  double* __restrict__ fld = lds + work_len;                       // [max_bh * max_bw]
+  double* __restrict__ qy = lds + fa.T.tile_cap;
+  double* __restrict__ fld = lds + fa.work_len;                    // [max_bh * max_bw]
   double* __restrict__ red = fld + fa.fld_len;                     // [kNW][4]
   double* __restrict__ red2 = red + 4 * kNW;                       // [32] proposal reductions
+  const int lds_xh4 = 4 * fa.P.lds_x_half;                         // the four coefficient planes; the [cos | sin] table follows
 
-  const StaticFields& S = a.S;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chain = blockIdx.x;
-  const int H = S.H, W = S.W;
-  const uint32_t ncells = (uint32_t)H * (uint32_t)W;
-  const size_t plane = (size_t)H * W;
-  const rsrc_t r_bed = make_rsrc((const TS*)a.beds + (size_t)chain * plane, ncells * (uint32_t)sizeof(TS));
-  const rsrc_t r_en = make_rsrc((const TS*)a.energy + (size_t)chain * plane, ncells * (uint32_t)sizeof(TS));
-  const rsrc_t r_rs = make_rsrc(a.resampled + (size_t)chain * plane, ncells * 4u);
-  const rsrc_t r_sA = make_rsrc(S.sA, ncells * 16u);
-  const rsrc_t r_sB = make_rsrc(S.sB, ncells * 16u);
-  const rsrc_t r_sC = make_rsrc(S.sC, ncells * 16u);
-  const rsrc_t r_sc = make_rsrc(pa.scalars + (size_t)chain * pa.n_steps, (uint32_t)pa.n_steps * (uint32_t)sizeof(PropScalars));
-  const uint64_t seed = pa.seeds[chain];
+  const int n_steps = fa.T.n_steps;
+  // buffer descriptors are rebuilt where they are used (a few scalar instructions) rather than held for the whole launch
+  auto plane_off = [&](cargs_t K) { return (size_t)chain * (size_t)K->T.S.H * (size_t)K->T.S.W; };
+  auto n_cells = [&](cargs_t K) { return (uint32_t)K->T.S.H * (uint32_t)K->T.S.W; };
+  auto rsrc_bed = [&](cargs_t K) { return make_rsrc((const TS*)K->T.beds + plane_off(K), n_cells(K) * (uint32_t)sizeof(TS)); };
+  auto rsrc_en = [&](cargs_t K) { return make_rsrc((const TS*)K->T.energy + plane_off(K), n_cells(K) * (uint32_t)sizeof(TS)); };
+  auto rsrc_rs = [&](cargs_t K) { return make_rsrc(K->T.resampled + plane_off(K), n_cells(K) * 4u); };
+  // the three packed static operands are one allocation: sA | sB | sC, selected by the scalar offset of the load
+  auto rsrc_st = [&](cargs_t K) { return make_rsrc(K->T.S.sA, 3u * n_cells(K) * 16u); };
+  auto rec_at = [&](cargs_t K, int step) -> crec_t {
+    return (crec_t)(uintptr_t)(K->P.scalars + (size_t)chain * K->P.n_steps + step);
+  };
+  const uint64_t seed = fa.P.seeds[chain];
 
-  double s_hi = a.loss_sum[2 * chain], s_lo = a.loss_sum[2 * chain + 1];
-  double loss_prev = (s_hi + s_lo) / S.two_sigma2;
+  double s_hi = fa.T.loss_sum[2 * chain], s_lo = fa.T.loss_sum[2 * chain + 1];
+  double loss_prev = (s_hi + s_lo) / fa.T.S.two_sigma2;
   // window of the previous step if it was accepted (its stores may still be in flight), else empty.  Older stores
   // are complete: vmcnt counts in order and every thread has since waited for younger loads of its own.
   int pr0 = 0, pr1 = 0, pc0 = 0, pc1 = 0;
@@ -106,97 +155,174 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
   unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
-  PropScalars sc_next = unpack_scalars((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_sc, (int)(lane < 26 ? 4u * lane : kOOB), 0, 0));
-  for (int s = 0; s < a.n_steps; ++s) {
+  const NoiseIn no_noise{nullptr, nullptr, nullptr};
+  // the fields of a record the proposal stages use
+  auto prop_rec = [&](crec_t r) {
+    PropScalars q;
+    q.scale = r->scale; q.nug = r->nug; q.aa = r->aa; q.m_const = r->m_const; q.m_kappa = r->m_kappa;
+    q.bh = r->bh; q.bw = r->bw; q.fy_off = r->fy_off; q.g_off = r->g_off; q.mask_off = r->mask_off;
+    return q;
+  };
+  {
+    // prologue: the coefficients of the launch's first step by all 16 waves straight into the LDS planes, its DFT tables by
+    // LDS-DMA; both are awaited at the first barrier of the step loop
+    const cargs_t K = kargs();
+    const ProposeArgs pa = load_c(&K->P);
+    const PropScalars q = prop_rec(rec_at(K, 0));
+    const PropGeom g0 = prop_geom(pa, q.bh, q.bw);
+    dma_to_lds<kNW, 0>(pa.tables + q.fy_off, lds + lds_xh4, 2 * g0.KR * g0.NR, wave, lane);
+    dma_to_lds<kNW, 0>(pa.tables + q.g_off, fld, 2 * g0.Kc * g0.M1, wave, lane);
+    coef_items<kNT, false>(tid, 0, g0.nrow * g0.ncol, true, pa, q, g0, seed, pa.step0, lds, pa.lds_x_half, no_noise);
+  }
+  for (int s = 0; s < n_steps; ++s) {
     STAMP(15);
-    const int64_t rout = (int64_t)chain * a.rec_stride + a.rec_offset + s;
-    const PropScalars sc = sc_next;
-    // record of step s + 1: issued now, unpacked after phase D (older than every load of this step, so complete by then)
-    const uint32_t nxt_dw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
-        r_sc, (int)((lane < 26 && s + 1 < a.n_steps) ? (uint32_t)(s + 1) * (uint32_t)sizeof(PropScalars) + 4u * lane : kOOB), 0, 0);
-    const int row = sc.row, col = sc.col, bh = sc.bh, bw = sc.bw;
-    const double uu = sc.u;
-
-    // window, clipped to the grid, and the matching sub-block of f (MCMC.py:1266-1276); halo (MCMC.py:1293-1297)
-    const int r0 = max(0, row - bh / 2), r1 = min(H, row + bh / 2);
-    const int c0 = max(0, col - bw / 2), c1 = min(W, col + bw / 2);
-    const int mr0 = max(bh - r1, 0), mc0 = max(bw - c1, 0);
-    const int wh = r1 - r0, ww = c1 - c0;
-    const int hr0 = max(0, r0 - 1), hr1 = min(H, r1 + 1);
-    const int hc0 = max(0, c0 - 1), hc1 = min(W, c1 + 1);
-    const int th = hr1 - hr0, tw = hc1 - hc0;
-    const int ncell = th * tw;
-    const uint32_t m_tw = magic_for((uint32_t)tw);
-    const int dr = r0 - hr0, dc = c0 - hc0;  // window origin inside the tile (0 or 1)
-
-    // stores of an earlier accepted step must have landed before this step reads an overlapping halo window
-    if ((hr0 < pr1) && (pr0 < hr1) && (hc0 < pc1) && (pc0 < hc1)) __syncthreads();
-
-    STAMP(0);
     // Geometry of the thread's tile cells t, t + 1024, ... by (magic) division; ptid is laundered per phase so that the
     // derived values are recomputed instead of being kept live across phases.  (An incremental form without the
     // multiplies measured 1.8 % slower on the same box.)
     int ptid = tid;
     asm volatile("" : "+v"(ptid));
-    auto cell = [&](int k, int& i, int& lr, int& lc, uint32_t& g, bool& valid, bool& inwin) {
-      i = ptid + k * kNT;
-      valid = i < ncell;
-      lr = (int)__umulhi((uint32_t)i, m_tw);
-      lc = i - lr * tw;
-      g = (uint32_t)((hr0 + lr) * W + hc0 + lc);
-      inwin = valid && (unsigned)(lr - dr) < (unsigned)wh && (unsigned)(lc - dc) < (unsigned)ww;
-    };
-    // Cell slot k of this WAVE holds tile cells 64 * wave + 1024 * k ...: past the end of the tile for the later slots of
-    // smaller blocks (on average 2.7 of the 7 slots).  Wave-uniform, so a scalar branch skips the whole slot in the
-    // stencil and commit phases.
-    auto slot_on = [&](int k) { return k * kNT + 64 * wave < ncell; };
     auto relaunder = [&] { asm volatile("" : "+v"(ptid)); };
+    auto win_of = [&](cargs_t K, crec_t r) { return make_win(K->T.S.H, K->T.S.W, r->row, r->col, r->bh, r->bw); };
+    auto cell = [&](const Win& G, int W, int k, int& i, int& lr, int& lc, uint32_t& g, bool& valid, bool& inwin) {
+      i = ptid + k * kNT;
+      valid = i < G.ncell;
+      lr = (int)__umulhi((uint32_t)i, G.m_tw);
+      lc = i - lr * G.tw;
+      g = (uint32_t)((G.hr0 + lr) * W + G.hc0 + lc);
+      inwin = valid && (unsigned)(lr - G.dr) < (unsigned)G.wh && (unsigned)(lc - G.dc) < (unsigned)G.ww;
+    };
 
-    // ---- P: proposal field -> LDS; P0 (inside, after the coefficient phase): chain state of the window -> registers,
-    // in flight during the two MFMA stages ---------------------------------------------------------------------
+    // ---- P0: chain state of the window -> registers --------------------------------------------------------------------
+    // The matrix-core waves request it now (the HBM latency runs under the two MFMA stages).  The coefficient waves request
+    // theirs when their items are done (it then flies under the standardisation): their item code needs the registers.
     double vb[KT], ve[KT];
-    STAMP(1);
-    propose_field<kNT, true, 2 * KT>(ptid, pa, sc, seed, pa.step0 + s, lds, red2, lds + 4 * pa.lds_x_half, fld,
-      [&] {
+    auto state_loads = [&] {
+      const cargs_t K = kargs();
+      const Win G = win_of(K, rec_at(K, s));
+      const rsrc_t r_bed = rsrc_bed(K);
+      const rsrc_t r_en = rsrc_en(K);
+      const int W = K->T.S.W;
 #pragma unroll
-        for (int k = 0; k < KT; ++k) {
-          int i, lr, lc; uint32_t g; bool valid, inwin;
-          cell(k, i, lr, lc, g, valid, inwin);
-          vb[k] = StateIO<TS>::load(r_bed, valid ? g * (uint32_t)sizeof(TS) : kOOB);
-          ve[k] = StateIO<TS>::load(r_en, inwin ? g * (uint32_t)sizeof(TS) : kOOB);
-        }
-      },
-      fld, [bw](int y, int x) { return y * bw + x; });
-#ifdef GSM_STAMPS
-    if (tid == 0) {
-      const unsigned long long* ps = (const unsigned long long*)(red2 + 32);
-      st_acc[10] += ps[10] - st_last; st_acc[11] += ps[11] - ps[10]; st_acc[12] += ps[12] - ps[11];
-      st_acc[13] += ps[13] - ps[12]; st_acc[14] += ps[14] - ps[13]; st_last = ps[14];
+      for (int k = 0; k < KT; ++k) {
+        int i, lr, lc; uint32_t g; bool valid, inwin;
+        cell(G, W, k, i, lr, lc, g, valid, inwin);
+        vb[k] = StateIO<TS>::load(r_bed, valid ? g * (uint32_t)sizeof(TS) : kOOB);
+        ve[k] = StateIO<TS>::load(r_en, inwin ? g * (uint32_t)sizeof(TS) : kOOB);
+      }
+    };
+    {
+      const cargs_t K = kargs();
+      const Win G = win_of(K, rec_at(K, s));
+      // stores of an earlier accepted step must have landed before this step reads an overlapping halo window
+      if ((G.hr0 < pr1) && (pr0 < G.hr1) && (G.hc0 < pc1) && (pc0 < G.hc1)) __syncthreads();
     }
-#endif
-    STAMP(2);
-    __syncthreads();
+    STAMP(0);
+    const bool more = s + 1 < n_steps;
+    double dc0;
+    // The two roles are two separate code paths from here to stage 2 (same barriers, in the same order, on both): what one
+    // role keeps in registers -- the chain state and the stage-1 accumulators on one side, the Box-Muller temporaries on the
+    // other -- is then not live on the other path.
+    if (wave >= kNWC) {
+      // ---- matrix-core waves ----
+      const int mw = wave - kNWC;
+      state_loads();
+      // Everything older than the 2 KT state loads -- the LDS-DMA of this step's coefficient planes and DFT tables (issued
+      // after phase D of the previous step, or by the prologue), the previous step's stores -- must have landed; vmcnt
+      // counts in order.  Then a bare barrier: __syncthreads() would wait vmcnt(0), i.e. for the HBM loads just issued.
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(2 * KT) : "memory");
+      STAMP(2);
+      dc0 = lds[0];    // mean of the field = DC coefficient / n (proposal_device.h); read before T^T overlays the plane
+      v4f64 uc[kUPW], us[kUPW];
+      {
+        const cargs_t K = kargs();
+        const ProposeArgs pa = load_c(&K->P);
+        const PropScalars q = prop_rec(rec_at(K, s));
+        dft_stage1<kNWM, kUPW, true>(mw, ptid & 63, pa, q, prop_geom(pa, q.bh, q.bw), lds, lds + lds_xh4, uc, us);
+      }
+      STAMP(1);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has finished reading the planes
+      STAMP(13);
+      {
+        const cargs_t K = kargs();
+        const ProposeArgs pa = load_c(&K->P);
+        crec_t r = rec_at(K, s);
+        relaunder();
+        dft_tt_write<kNWM, kUPW>(mw, ptid & 63, prop_geom(pa, r->bh, r->bw), lds, uc, us);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      STAMP(10);
+    } else {
+      // ---- coefficient waves: step s + 1 (about two thirds of its items beside stage 1, the rest beside stage 2) ----
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      STAMP(2);
+      dc0 = lds[0];
+      auto items = [&](const int part) {
+        relaunder();
+        const cargs_t K = kargs();
+        const ProposeArgs pa = load_c(&K->P);
+        const PropScalars q = prop_rec(rec_at(K, s + 1));
+        const PropGeom gn = prop_geom(pa, q.bh, q.bw);
+        const int n_item = gn.nrow * gn.ncol;
+        const int passes = (n_item + kNTV - 1) / kNTV;
+        const int n_split = min(n_item, ((2 * passes + 2) / 3) * kNTV);
+        coef_items<kNTV, false>(ptid, part ? n_split : 0, part ? n_item : n_split, part == 0, pa, q, gn, seed,
+                                pa.step0 + s + 1, K->coef + (size_t)chain * 4 * pa.lds_x_half, pa.lds_x_half, no_noise);
+      };
+      __builtin_amdgcn_s_setprio(2);
+      if (more) items(0);
+      __builtin_amdgcn_s_setprio(0);
+      STAMP(1);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      STAMP(13);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      STAMP(10);
+      __builtin_amdgcn_s_setprio(2);
+      if (more) items(1);
+      __builtin_amdgcn_s_setprio(0);
+      relaunder();
+      state_loads();       // lands under stage 2 / the standardisation
+    }
+    // ---- S2: stage 2, output tile t on wave t of all 16 (at most 16 tiles; 12 or fewer for most block shapes, so the
+    // coefficient waves seldom own one) -----------------------------------------------------------------------------------
+    {
+      const cargs_t K = kargs();
+      const ProposeArgs pa = load_c(&K->P);
+      const PropScalars q = prop_rec(rec_at(K, s));
+      const PropGeom pg = prop_geom(pa, q.bh, q.bw);
+      const int bw = q.bw;
+      v4f64 fe[1], fo[1];
+      double mreg[1][8];
+      relaunder();
+      const int ln = ptid & 63;
+      dft_stage2<kNW, 1, true>(wave, ln, pa, q, pg, lds, fld, fe, fo);
+      mask_prefetch<kNW, 1>(wave, ln, pa, q, pg, mreg);
+      STAMP(11);
+      double mean;
+      const double gain = standardise<kNW, 1>(wave, ln, q, pg, dc0, red2, fe, fo, mean);     // contains a barrier
+      STAMP(14);
+      const bool with_nugget = pa.rf.nugget_max > 0.0;
+      emit_field<kNW, 1, true>(wave, ln, pa, q, pg, fe, fo, mreg, mean, gain, with_nugget, fld, [bw](int y, int x) { return y * bw + x; });
+      if (with_nugget) {
+        __syncthreads();
+        relaunder();
+        nugget_pass<kNT, false>(ptid, pa, q, pg, seed, pa.step0 + s, no_noise, fld, [bw](int y, int x) { return y * bw + x; });
+      }
+    }
+    STAMP(12);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // field tile complete
     STAMP(3);
 
-    // ---- A: candidate bed, fluxes -> LDS, guard, carried energy of the window ---------------------------
+    // ---- A: candidate bed, fluxes -> LDS, guard ---------------------------------------------------------------------
     double v_new[KT];
     uint32_t upd_bits = 0;
-    double acc_old = 0.0;
     int guard = 0;
     relaunder();
     // Geometry for phases A, D and E, computed once per step after the proposal and kept packed in two registers per
     // cell: gq = flat grid index, rq = tile row | tile col << 8 | valid << 16 | in-window << 17 (+1.9 % over recomputing
     // it in every phase, same box).  The arrays are laundered per phase so that only they stay live across phases.
     uint32_t gq[KT], rq[KT];
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      int i, lr, lc; uint32_t g; bool valid, inwin;
-      cell(k, i, lr, lc, g, valid, inwin);
-      gq[k] = g;
-      rq[k] = (uint32_t)lr | ((uint32_t)lc << 8) | (valid ? 1u << 16 : 0u) | (inwin ? 1u << 17 : 0u);
-    }
     auto cellq = [&](int k, int& i, int& lr, int& lc, uint32_t& g, bool& valid, bool& inwin) {
-      i = tid + k * kNT; g = gq[k];
+      i = ptid + k * kNT; g = gq[k];
       lr = (int)(rq[k] & 0xFFu); lc = (int)((rq[k] >> 8) & 0xFFu);
       valid = (rq[k] >> 16) & 1u; inwin = (rq[k] >> 17) & 1u;
     };
@@ -204,57 +330,77 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
 #pragma unroll
       for (int k = 0; k < KT; ++k) asm volatile("" : "+v"(gq[k]), "+v"(rq[k]));
     };
-    constexpr int KB = (KT > 4) ? 2 : KT;      // cells per sub-batch of phase A (2: +0.8 % over 4, same box)
-#pragma unroll
-    for (int kb = 0; kb < KT; kb += KB) {
-      if (kb > 0 && !slot_on(kb)) break;   // this wave has no cell in this sub-batch nor in any later one
-      double vf[KB];
-      double2 A2[KB], B2[KB];
-#pragma unroll
-      for (int j = 0; j < KB; ++j) {
-        const int k = kb + j;
-        if (k < KT) {
-          int i, lr, lc; uint32_t g; bool valid, inwin;
-          cellq(k, i, lr, lc, g, valid, inwin);
-          A2[j] = ld_f64x2(r_sA, valid ? g * 16u : kOOB);   // (wupd, surf)
-          B2[j] = ld_f64x2(r_sB, valid ? g * 16u : kOOB);   // (velx, vely)
-          vf[j] = inwin ? fld[(mr0 + lr - dr) * bw + mc0 + lc - dc] : 0.0;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < KB; ++j) {
-        const int k = kb + j;
-        if (k < KT) {
-          int i, lr, lc; uint32_t g; bool valid, inwin;
-          cellq(k, i, lr, lc, g, valid, inwin);
-          const bool upd = inwin && (__builtin_bit_cast(uint64_t, A2[j].x) != kNoUpdBits);
-          upd_bits |= upd ? (1u << k) : 0u;
-          double v = vb[k];
-          if (upd) {
-            v = v + vf[j] * A2[j].x;
-            if (F32) v = (double)(float)v;
-          }
-          const double thick = A2[j].y - v;
-          if (upd && thick <= 0.0) guard = 1;
-          v_new[k] = v;
-          acc_old += ve[k];
-          if (valid) {
-            qx[i] = B2[j].x * thick;
-            qy[i] = B2[j].y * thick;
-          }
-        }
-      }
-      asm volatile("" : "+v"(acc_old));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // (dhdt_mc, smb) of the window cells: issued before the barrier, in flight across it
+    // Cell slot k of this WAVE holds tile cells 64 * wave + 1024 * k ...: past the end of the tile for the later slots of
+    // smaller blocks (on average 2.7 of the 7 slots).  Wave-uniform, so a scalar branch skips the whole slot in the
+    // stencil and commit phases.
     double2 C2[KT];
-    launderq();
+    double acc_old = 0.0;
+    {
+      const cargs_t K = kargs();
+      crec_t r = rec_at(K, s);
+      const Win G = win_of(K, r);
+      const int bw = r->bw, W = K->T.S.W;
+      const uint32_t off_sB = n_cells(K) * 16u, off_sC = 2u * off_sB;
+      auto slot_on = [&](int k) { return k * kNT + 64 * wave < G.ncell; };
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      int i, lr, lc; uint32_t g; bool valid, inwin;
-      cellq(k, i, lr, lc, g, valid, inwin);
-      C2[k] = ld_f64x2(r_sC, inwin ? g * 16u : kOOB);
+      for (int k = 0; k < KT; ++k) {
+        int i, lr, lc; uint32_t g; bool valid, inwin;
+        cell(G, W, k, i, lr, lc, g, valid, inwin);
+        gq[k] = g;
+        rq[k] = (uint32_t)lr | ((uint32_t)lc << 8) | (valid ? 1u << 16 : 0u) | (inwin ? 1u << 17 : 0u);
+      }
+      const rsrc_t r_st = rsrc_st(K);
+      constexpr int KB = (KT > 4) ? 2 : KT;      // cells per sub-batch of phase A (2: +0.8 % over 4, same box)
+#pragma unroll
+      for (int kb = 0; kb < KT; kb += KB) {
+        if (kb > 0 && !slot_on(kb)) break;   // this wave has no cell in this sub-batch nor in any later one
+        double vf[KB];
+        double2 A2[KB], B2[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+          const int k = kb + j;
+          if (k < KT) {
+            int i, lr, lc; uint32_t g; bool valid, inwin;
+            cellq(k, i, lr, lc, g, valid, inwin);
+            A2[j] = ld_f64x2(r_st, valid ? g * 16u : kOOB, 0u);       // (wupd, surf)
+            B2[j] = ld_f64x2(r_st, valid ? g * 16u : kOOB, off_sB);   // (velx, vely)
+            vf[j] = inwin ? fld[(G.mr0 + lr - G.dr) * bw + G.mc0 + lc - G.dc] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+          const int k = kb + j;
+          if (k < KT) {
+            int i, lr, lc; uint32_t g; bool valid, inwin;
+            cellq(k, i, lr, lc, g, valid, inwin);
+            const bool upd = inwin && (__builtin_bit_cast(uint64_t, A2[j].x) != kNoUpdBits);
+            upd_bits |= upd ? (1u << k) : 0u;
+            double v = vb[k];
+            if (upd) {
+              v = v + vf[j] * A2[j].x;
+              if (F32) v = (double)(float)v;
+            }
+            const double thick = A2[j].y - v;
+            if (upd && thick <= 0.0) guard = 1;
+            v_new[k] = v;
+            acc_old += ve[k];
+            if (valid) {
+              qx[i] = B2[j].x * thick;
+              qy[i] = B2[j].y * thick;
+            }
+          }
+        }
+        asm volatile("" : "+v"(acc_old));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // (dhdt_mc, smb) of the window cells: issued before the barrier, in flight across it
+      launderq();
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        int i, lr, lc; uint32_t g; bool valid, inwin;
+        cellq(k, i, lr, lc, g, valid, inwin);
+        C2[k] = ld_f64x2(r_st, inwin ? g * 16u : kOOB, off_sC);
+      }
     }
     STAMP(4);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS tiles complete; the loads above stay in flight
@@ -264,50 +410,56 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     double e_new[KT];
     double acc_new = 0.0;
     launderq();
-    // interior step (a halo ring on all four sides, ~5 steps in 6): no window cell touches a grid border, every
-    // difference is central.  The general form applies np.gradient's one-sided edge rules.
-    const bool interior = (hr0 < r0) && (hr1 > r1) && (hc0 < c0) && (hc1 > c1);
-    auto phase_d = [&](auto interior_tag) {
-      constexpr bool INTERIOR = decltype(interior_tag)::value;
+    {
+      const cargs_t K = kargs();
+      const StaticFields S = load_c(&K->T.S);
+      const int H = S.H, W = S.W;
+      const Win G = win_of(K, rec_at(K, s));
+      const int tw = G.tw, hr0 = G.hr0, hc0 = G.hc0;
+      auto slot_on = [&](int k) { return k * kNT + 64 * wave < G.ncell; };
+      // interior step (a halo ring on all four sides, ~5 steps in 6): no window cell touches a grid border, every
+      // difference is central.  The general form applies np.gradient's one-sided edge rules.
+      const bool interior = (G.hr0 < G.r0) && (G.hr1 > G.r1) && (G.hc0 < G.c0) && (G.hc1 > G.c1);
+      auto phase_d = [&](auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        if (!slot_on(k)) { e_new[k] = 0.0; continue; }
-        int i, lr, lc; uint32_t g; bool valid, inwin;
-        cellq(k, i, lr, lc, g, valid, inwin);
-        double e = 0.0;
-        if (inwin) {
-          double dx, dy;
-          if (INTERIOR) {
-            const double ddx = qx[i + 1] - qx[i - 1];
-            const double ddy = qy[i + tw] - qy[i - tw];
-            if (FAST_DIV) { dx = exact_div(ddx, S.two_res, S.rcp_two_res); dy = exact_div(ddy, S.two_res, S.rcp_two_res); }
-            else { dx = ddx / S.two_res; dy = ddy / S.two_res; }
-          } else {
-            const int r = hr0 + lr, c = hc0 + lc;
-            const int il = (c == 0) ? i : i - 1, ir = (c == W - 1) ? i : i + 1;
-            const int iu = (r == 0) ? i : i - tw, id = (r == H - 1) ? i : i + tw;
-            const double ddx = qx[ir] - qx[il];
-            const double ddy = qy[id] - qy[iu];
-            if (FAST_DIV) {
-              dx = (ir - il == 2) ? exact_div(ddx, S.two_res, S.rcp_two_res) : exact_div(ddx, S.res, S.rcp_res);
-              dy = (id - iu == 2 * tw) ? exact_div(ddy, S.two_res, S.rcp_two_res) : exact_div(ddy, S.res, S.rcp_res);
+        for (int k = 0; k < KT; ++k) {
+          if (!slot_on(k)) { e_new[k] = 0.0; continue; }
+          int i, lr, lc; uint32_t g; bool valid, inwin;
+          cellq(k, i, lr, lc, g, valid, inwin);
+          double e = 0.0;
+          if (inwin) {
+            double dx, dy;
+            if (INTERIOR) {
+              const double ddx = qx[i + 1] - qx[i - 1];
+              const double ddy = qy[i + tw] - qy[i - tw];
+              if (FAST_DIV) { dx = exact_div(ddx, S.two_res, S.rcp_two_res); dy = exact_div(ddy, S.two_res, S.rcp_two_res); }
+              else { dx = ddx / S.two_res; dy = ddy / S.two_res; }
             } else {
-              dx = ddx / ((ir - il == 2) ? S.two_res : S.res);
-              dy = ddy / ((id - iu == 2 * tw) ? S.two_res : S.res);
+              const int r = hr0 + lr, c = hc0 + lc;
+              const int il = (c == 0) ? i : i - 1, ir = (c == W - 1) ? i : i + 1;
+              const int iu = (r == 0) ? i : i - tw, id = (r == H - 1) ? i : i + tw;
+              const double ddx = qx[ir] - qx[il];
+              const double ddy = qy[id] - qy[iu];
+              if (FAST_DIV) {
+                dx = (ir - il == 2) ? exact_div(ddx, S.two_res, S.rcp_two_res) : exact_div(ddx, S.res, S.rcp_res);
+                dy = (id - iu == 2 * tw) ? exact_div(ddy, S.two_res, S.rcp_two_res) : exact_div(ddy, S.res, S.rcp_res);
+              } else {
+                dx = ddx / ((ir - il == 2) ? S.two_res : S.res);
+                dy = ddy / ((id - iu == 2 * tw) ? S.two_res : S.res);
+              }
             }
+            const double v = ((dx + dy) + C2[k].x) - C2[k].y;
+            if (!isnan(v)) e = v * v;
+            if (F32) e = (double)(float)e;
           }
-          const double v = ((dx + dy) + C2[k].x) - C2[k].y;
-          if (!isnan(v)) e = v * v;
-          if (F32) e = (double)(float)e;
+          e_new[k] = e;
+          acc_new += e;
+          if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
-        e_new[k] = e;
-        acc_new += e;
-        if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    if (interior) phase_d(std::true_type{}); else phase_d(std::false_type{});
-
-    sc_next = unpack_scalars(nxt_dw);
+      };
+      if (interior) phase_d(std::true_type{}); else phase_d(std::false_type{});
+    }
     STAMP(6);
     // ---- R: reduce, decide (every thread evaluates the same numbers in the same order) ----------------
     {
@@ -321,8 +473,19 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       }
     }
     STAMP(7);
-    __syncthreads();
+    __syncthreads();      // also: every wave is past phase D (flux tiles dead) and the coefficient waves' stores have landed
     STAMP(8);
+    if (more) {
+      // next step's coefficient planes (scratch -> LDS, past L1: they were written by other waves of this CU) and DFT
+      // tables, by LDS-DMA; they fly under the accept test and the commit and are awaited at the next step's first barrier
+      const cargs_t K = kargs();
+      const ProposeArgs pa = load_c(&K->P);
+      crec_t rn = rec_at(K, s + 1);
+      const PropGeom gn = prop_geom(pa, rn->bh, rn->bw);
+      dma_to_lds<kNW, 2>(K->coef + (size_t)chain * lds_xh4, lds, lds_xh4, wave, lane);
+      dma_to_lds<kNW, 0>(pa.tables + rn->fy_off, lds + lds_xh4, 2 * gn.KR * gn.NR, wave, lane);
+      dma_to_lds<kNW, 0>(pa.tables + rn->g_off, fld, 2 * gn.Kc * gn.M1, wave, lane);
+    }
     const int rl = (lane & 15) * 4;
     const double so = row16_sum(red[rl]);
     const double sn = row16_sum(red[rl + 1]);
@@ -330,14 +493,21 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     double c_hi, c_err;
     two_sum(s_hi, sn - so, c_hi, c_err);
     const double c_lo = s_lo + c_err;
-    double loss_next = (c_hi + c_lo) / S.two_sigma2;
+    const cargs_t Ke = kargs();
+    double loss_next = (c_hi + c_lo) / Ke->T.S.two_sigma2;
     if (gd > 0.0) loss_next = INFINITY;
     const double p_acc = (loss_prev > loss_next) ? 1.0 : fmin(1.0, exp(loss_prev - loss_next));
-    const bool acc = (uu <= p_acc);
+    crec_t rc = rec_at(Ke, s);
+    const bool acc = (rc->u <= p_acc);
 
     // ---- E: commit -------------------------------------------------------------------------------------
     if (acc) {
       launderq();
+      const Win G = win_of(Ke, rc);
+      auto slot_on = [&](int k) { return k * kNT + 64 * wave < G.ncell; };
+      const rsrc_t r_bed = rsrc_bed(Ke);
+      const rsrc_t r_en = rsrc_en(Ke);
+      const rsrc_t r_rs = rsrc_rs(Ke);
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         if (!slot_on(k)) continue;
@@ -350,23 +520,25 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       }
       two_sum(c_hi, c_lo, s_hi, s_lo);
       loss_prev = loss_next;
-      pr0 = r0; pr1 = r1; pc0 = c0; pc1 = c1;
+      pr0 = G.r0; pr1 = G.r1; pc0 = G.c0; pc1 = G.c1;
     } else {
       pr0 = pr1 = pc0 = pc1 = 0;
     }
     STAMP(9);
     if (tid == 0) {
+      const StepArgs a = load_c(&Ke->T);
+      const int64_t rout = (int64_t)chain * a.rec_stride + a.rec_offset + s;
       a.loss[rout] = loss_prev;
       a.accept[rout] = acc ? 1 : 0;
-      if (a.blocks) { a.blocks[4 * rout] = row; a.blocks[4 * rout + 1] = col; a.blocks[4 * rout + 2] = bh; a.blocks[4 * rout + 3] = bw; }
+      if (a.blocks) { a.blocks[4 * rout] = rc->row; a.blocks[4 * rout + 1] = rc->col; a.blocks[4 * rout + 2] = rc->bh; a.blocks[4 * rout + 3] = rc->bw; }
     }
   }
   if (tid == 0) {
-    a.loss_sum[2 * chain] = s_hi;
-    a.loss_sum[2 * chain + 1] = s_lo;
+    fa.T.loss_sum[2 * chain] = s_hi;
+    fa.T.loss_sum[2 * chain + 1] = s_lo;
   }
 #ifdef GSM_STAMPS
-  if (tid == 0 && chain < 4096) for (int q = 0; q < 16; ++q) g_stamps_fused[chain * 16 + q] = st_acc[q];
+  if (tid == GSM_STAMP_TID && chain < 4096) for (int q = 0; q < 16; ++q) g_stamps_fused[chain * 16 + q] = st_acc[q];
 #endif
 }
 
@@ -397,7 +569,8 @@ static hipError_t launch_fused_t(const FusedArgs& a, hipStream_t st) {
 }
 
 bool fused_supported(const FusedArgs& a) {
-  return step_flux_supported(a.T) && a.P.tab_max > 0 && fused_lds_doubles(a) * sizeof(double) <= 160 * 1024;
+  return step_flux_supported(a.T) && a.P.tab_max > 0 && fused_lds_doubles(a) * sizeof(double) <= 160 * 1024 &&
+         2 * a.P.tiles1_max <= kNWM * kUPW && a.P.tiles2_max <= 16;
 }
 
 // One launch: propose_scalars_kernel for all steps must have filled a.P.scalars (n_chains x a.P.n_steps records).

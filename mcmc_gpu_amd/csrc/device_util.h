@@ -28,8 +28,8 @@ template <int AUX>
 __device__ __forceinline__ float ld_f32(rsrc_t r, uint32_t off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, AUX));
 }
-__device__ __forceinline__ double2 ld_f64x2(rsrc_t r, uint32_t off) {
-  const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+__device__ __forceinline__ double2 ld_f64x2(rsrc_t r, uint32_t off, uint32_t soff = 0u) {   // soff: uniform byte offset
+  const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, (int)soff, 0);
   double2 d;
   d.x = __builtin_bit_cast(double, v2i32{v.x, v.y});
   d.y = __builtin_bit_cast(double, v2i32{v.z, v.w});

@@ -26,6 +26,8 @@ struct gsm_context {
   int32_t *d_fy_off = nullptr, *d_g_off = nullptr;
   int lds_sx = 0, lds_st = 0, lds_x_half = 0, lds_tt = 0, prop_tiles = 0, prop_tiles1 = 0;
   int tables_len = 0, tab_max = 0;
+  double* d_coef = nullptr;      // fused chain kernel: coefficient planes of the next step, [n_chains][4 * lds_x_half]
+  size_t coef_cap = 0;
   PropScalars* d_scalars[2] = {nullptr, nullptr};
   size_t scalars_cap[2] = {0, 0};
   // Cholesky generator
@@ -114,9 +116,7 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_svx) hipFree(h->d_svx);
   if (h->d_svy) hipFree(h->d_svy);
   if (h->d_ds) hipFree(h->d_ds);
-  if (h->d_sA) hipFree(h->d_sA);
-  if (h->d_sB) hipFree(h->d_sB);
-  if (h->d_sC) hipFree(h->d_sC);
+  if (h->d_sA) hipFree(h->d_sA);      // d_sB, d_sC point into the same allocation
   if (h->d_bh) hipFree(h->d_bh);
   if (h->d_bw) hipFree(h->d_bw);
   if (h->d_mask_off) hipFree(h->d_mask_off);
@@ -125,6 +125,7 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_fy_off) hipFree(h->d_fy_off);
   if (h->d_g_off) hipFree(h->d_g_off);
   for (auto& p : h->d_scalars) if (p) hipFree(p);
+  if (h->d_coef) hipFree(h->d_coef);
   if (h->d_factors) hipFree(h->d_factors);
   for (auto& c : h->chol) { if (c.ints) hipFree(c.ints); if (c.zoff) hipFree(c.zoff); if (c.per_rec) hipFree(c.per_rec);
                             if (c.scale) hipFree(c.scale); if (c.zbuf) hipFree(c.zbuf); }
@@ -188,9 +189,9 @@ extern "C" int gsm_set_static(gsm_handle h, const double* surf, const double* ve
     HIPCHK(h, hipMalloc(&h->d_svx, n * sizeof(double2)));
     HIPCHK(h, hipMalloc(&h->d_svy, n * sizeof(double2)));
     HIPCHK(h, hipMalloc(&h->d_ds, n * sizeof(double2)));
-    HIPCHK(h, hipMalloc(&h->d_sA, n * sizeof(double2)));
-    HIPCHK(h, hipMalloc(&h->d_sB, n * sizeof(double2)));
-    HIPCHK(h, hipMalloc(&h->d_sC, n * sizeof(double2)));
+    HIPCHK(h, hipMalloc(&h->d_sA, 3 * n * sizeof(double2)));      // sA | sB | sC in one allocation (one buffer descriptor)
+    h->d_sB = h->d_sA + n;
+    h->d_sC = h->d_sA + 2 * n;
   }
   HIPCHK(h, launch_pack_static(S, h->d_svx, h->d_svy, h->d_ds, st));
   HIPCHK(h, launch_pack_flux_static(S, h->d_sA, h->d_sB, h->d_sC, st));
@@ -281,7 +282,7 @@ extern "C" int gsm_set_blocks(gsm_handle h, int32_t n_sizes, const int32_t* bh, 
   auto stride16mod32 = [](int v) { int s = v; while ((s & 31) != 16) ++s; return s; };
   h->lds_sx = stride16mod32(m1max);
   h->lds_st = stride16mod32(n1max);
-  h->lds_x_half = krmax * h->lds_sx;          // one of the four folded coefficient planes
+  h->lds_x_half = (krmax * h->lds_sx + 127) & ~127;   // one of the four folded coefficient planes; whole 1 KiB LDS-DMA pieces
   h->lds_tt = 2 * kcmax * h->lds_st;
   h->prop_tiles = tiles_max;
   h->tables_len = (int)tb.size();
@@ -429,6 +430,7 @@ static ProposeArgs make_propose(gsm_handle h, const gsm_rf_params* rf, int n_ste
   p.tables = h->d_tables; p.tables_len = h->tables_len; p.tab_max = h->tab_max; p.fy_off = h->d_fy_off; p.g_off = h->d_g_off;
   p.lds_sx = h->lds_sx; p.lds_st = h->lds_st; p.lds_x_half = h->lds_x_half; p.lds_tt = h->lds_tt;
   p.lds_main = std::max(4 * h->lds_x_half, h->lds_tt);
+  p.tiles1_max = h->prop_tiles1; p.tiles2_max = h->prop_tiles;
   return p;
 }
 
@@ -559,6 +561,13 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
         HIPCHK(h, hipMalloc(&sc.u, recs1 * sizeof(double)));
         sc.recs = recs1;
       }
+      const size_t coef_need = (size_t)h->n_chains * 4 * (size_t)h->lds_x_half;
+      if (h->coef_cap < coef_need) {
+        if (h->d_coef) { hipFree(h->d_coef); h->d_coef = nullptr; h->coef_cap = 0; }
+        HIPCHK(h, hipMalloc(&h->d_coef, coef_need * sizeof(double)));
+        h->coef_cap = coef_need;
+      }
+      fa.coef = h->d_coef;
       const int n_seg = (n_steps + seg_max - 1) / seg_max;
       std::vector<hipEvent_t> tev;
       if (h->timing) { tev.resize((size_t)2 * n_seg); for (auto& e : tev) HIPCHK(h, hipEventCreate(&e)); }

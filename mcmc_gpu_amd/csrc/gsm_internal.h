@@ -101,7 +101,8 @@ struct ProposeArgs {
   int lds_sx, lds_st;      // LDS row strides of X and T^T (== 16 mod 32 doubles: conflict-free fragment reads)
   int lds_x_half;          // doubles per X plane (re or im)
   int lds_tt;              // doubles of T^T
-  int lds_main;            // max(2 * lds_x_half, lds_tt): T^T overlays X
+  int lds_main;            // max(4 * lds_x_half, lds_tt): T^T overlays X
+  int tiles1_max, tiles2_max;  // largest stage-1 / stage-2 output-tile counts over the block table
   PropScalars* scalars;    // device scratch, n_chains * n_steps records
   int dbg;                 // diagnostics only (GSM_PROPOSE_DBG): bit0 cheap coefficients, bit1 skip stage 1, bit2 skip stage 2
 };
@@ -111,6 +112,8 @@ struct FusedArgs {
   StepArgs T;
   ProposeArgs P;
   int work_len, fld_len;   // LDS region sizes in doubles, set by launch_chain_fused
+  double* coef;            // [n_chains][4 * lds_x_half]: coefficient planes of the NEXT step, written by the four coefficient
+                           // waves while the other twelve run the matrix-core stages of the current one (L2-resident)
 };
 
 // scratch + factor table of the Cholesky proposal generator (cholesky_kernel.hip)

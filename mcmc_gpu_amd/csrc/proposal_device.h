@@ -1,7 +1,6 @@
-// Spectral proposal field of one (chain, step) on one workgroup of NT threads (NT = 512: stand-alone proposal kernel,
-// two workgroups per CU; NT = 1024: inside the fused chain kernel).  See proposal_kernel.hip for the algorithm
-// (reference gstatsMCMC/MCMC.py:742-778, :176-254).  The arithmetic of every field value -- including the order of the
-// two reductions of the standardisation -- does not depend on NT, so both forms produce bit-identical fields.
+// Spectral proposal field of one (chain, step), as a sequence of stage functions shared by the stand-alone proposal kernel
+// (512 threads, two workgroups per CU) and the fused chain kernel.  See proposal_kernel.hip for the algorithm
+// (reference gstatsMCMC/MCMC.py:742-778, :176-254).
 #pragma once
 #ifndef PSTAMP
 #define PSTAMP(slot) do {} while (0)
@@ -95,23 +94,6 @@ __device__ __forceinline__ double wavenumber(int k, int n, double inv) {
   return ((double)kk * inv) * 2.0 * M_PI;
 }
 
-// Sum over the workgroup of per-tile partials: tile t is reduced by the wave that owns it (fixed lane order, DPP),
-// then the 16 tile slots are added by a fixed DPP tree in every thread.  red: 16 doubles of LDS, not reused before the
-// next barrier.
-template <int NT>
-__device__ __forceinline__ double tiles_sum(const double (&part)[16 / (NT / 64)], int n_tiles, double* red, int tid) {
-  constexpr int NW = NT / 64, MAXT = 16 / NW;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#pragma unroll
-  for (int j = 0; j < MAXT; ++j) {
-    const double w = dev::wave64_sum(part[j]);
-    const int t = wave + j * NW;
-    if ((tid & 63) == 0) red[t] = (t < n_tiles) ? w : 0.0;   // all 16 slots are written
-  }
-  __syncthreads();
-  return dev::row16_sum(red[tid & 15]);   // fixed tree over the 16 tile slots: the same value in every lane
-}
-
 // sqrt(S(k)) of MCMC.py:227-239, :244
 __device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const PropScalars& sc, int ky, int kx, int bh, int bw,
                                               double inv_x, double inv_y) {
@@ -131,104 +113,92 @@ __device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const Pro
 // for k in {0, h}):   sum_k X[k] e^{+i t k y} = U[y] + i V[y],  U = sum_{k<=h} P[k] cos(t k y),  V = sum_{k<h} M[k] sin(t k y)
 // and the mirrored output is  U[y] - i V[y]  at n - y.  Only k, y in [0, h] enter the products: 4x fewer flops than the
 // dense complex DFT.  The real (c2r) stage folds the same way in x: field[y][x] = E + O, field[y][bw - x] = E - O.
-// plds: LDS work area of a.lds_main doubles (the four coefficient planes, overlaid by T^T); red: 32 doubles of LDS.
-// out: receives the finished (scaled, masked) field (global memory or LDS): cell (y, x) goes to out[omap(y, x)], or
-// nowhere if omap returns a negative index (the 512-thread fused kernel stores only the part of the block inside the
-// grid, at its position in the window tile).
-// Contains workgroup barriers: every thread of the workgroup must call it with the same (uniform) arguments.  On return
-// other waves may still be reading `red`; the planes are free once every wave has returned.
 //
-// TABLDS (fused chain kernel, one workgroup per CU): the DFT operand tables of this block shape are staged in LDS --
-// tabA ([cos | sin] of the block height, 2*KR*NR doubles) must not overlap the planes, tabG (folded c2r table of the
-// block width, 2*Kc*M1 doubles) must not overlap planes, T^T or tabA and may overlap `out` -- so the MFMA loops read
-// both operands from LDS, and the edge-mask loads are issued one phase ahead of their use.  Arithmetic identical to the
-// global-table form.
+// The proposal is a sequence of stages, each a function below; a stage is executed by NW waves of the workgroup and `w`
+// is the calling wave's index among them (tile / unit ownership: unit u belongs to wave u mod NW).  Callers:
+//   propose_field<NT>        all NT / 64 waves run every stage in turn (stand-alone proposal kernel, gsm_spectral_from_noise)
+//   chain_fused_kernel       12 waves run the matrix-core stages of step s while the other 4 compute the coefficients of
+//                            step s + 1 (chain_fused_kernel.hip)
+// The arithmetic of every field value -- including the order of the two reductions of the standardisation -- does not
+// depend on NW, so all forms produce bit-identical fields.
+//
+// LDS: four coefficient planes [KRmax][SX] (P re, P im, M re, M im), overlaid by T^T [2 Kc][ST] once stage 1 has consumed
+// them; `red`: 32 doubles.  TABLDS: the DFT operand tables of this block shape are staged in LDS -- tabA ([cos | sin] of the
+// block height, 2*KR*NR doubles) must not overlap the planes, tabG (folded c2r table of the block width, 2*Kc*M1 doubles)
+// must not overlap planes, T^T or tabA and may overlap the output -- so the MFMA loops read both operands from LDS.
 
-// after_coeff(): called by every thread once its share of the coefficient phase is done (before the first barrier); it
-// must issue exactly HOOK_VMEM vector-memory instructions --
-// the fused kernel issues the loads of the chain state there, so that they fly during the two MFMA stages without
-// occupying registers during the register-hungry coefficient phase.
-//
 // NOISE_IN (gsm_spectral_from_noise, the value pin against the reference): the coefficients are not drawn but formed from
 // caller-supplied white-noise planes N1, N2 of the full (bh, bw) spectrum, X[k] = amp(k) ((N1[k] + N1[-k])/2 +
 // i (N2[k] - N2[-k])/2) -- the Hermitian part of the reference's (N1 + i N2) sqrt(S) (MCMC.py:242-247) -- and the nugget
 // term is the caller's rng.normal(0, sqrt(nug)) plane.  Everything downstream of the coefficients is the same code.
 struct NoiseIn { const double* re; const double* im; const double* nug; };
 
-template <int NT, bool TABLDS, int HOOK_VMEM, bool NOISE_IN = false, class Hook, class OMap>
-__device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& a, const PropScalars& sc, const uint64_t seed,
-                                              const int64_t step, double* plds, double* red, double* tabA, double* tabG, Hook after_coeff,
-                                              double* __restrict__ out, OMap omap, const NoiseIn noise = NoiseIn{nullptr, nullptr, nullptr}) {
-  constexpr int NW = NT / 64, MAXT = 16 / NW;
-  const int SX = a.lds_sx, ST = a.lds_st;
-  double* Pr = plds;                       // 4 planes [KRmax][SX]: P re, P im, M re, M im
-  double* Pi = Pr + a.lds_x_half;
-  double* Mr = Pi + a.lds_x_half;
-  double* Mi = Mr + a.lds_x_half;
-  double* TT = plds;                       // [2 Kc][ST]  -- overlays the planes once stage 1 has consumed them
-  const int lane = tid & 63;
-  // wave index as a scalar: tile / unit ownership, the divisions t % n, t / n and the ownership branches then run on the
-  // scalar unit instead of the vector pipe
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // tid: threadIdx.x (the fused kernel passes a per-step copy the
-  const gsm_rf_params& P = a.rf;                // compiler cannot hoist thread-dependent values out of its step loop with)
-  const int bh = sc.bh, bw = sc.bw;
-  const int hh = bh / 2, hw = bw / 2;
-  const int ncol = hw + 1, nrow = hh + 1;
+// shape-derived sizes of one proposal (the host builds the tables with the same formulas)
+struct PropGeom {
+  int bh, bw, hh, hw, ncol, nrow;
+  int KR;   // stage-1 K  (ky <= hh), multiple of 4
+  int NR;   // stage-1 N  (y  <= hh), multiple of 16
+  int M1;   // stage-1 M  (kx)  = stage-2 N (x <= hw), multiple of 16
+  int Kc;   // stage-2 K per half (re | im rows of T^T), multiple of 4
+  int N1;   // stage-2 M  (y), multiple of 16
+  int SX, ST;
+};
+__device__ __forceinline__ PropGeom prop_geom(const ProposeArgs& a, int bh, int bw) {
+  PropGeom g;
+  g.bh = bh; g.bw = bw; g.hh = bh / 2; g.hw = bw / 2;
+  g.ncol = g.hw + 1; g.nrow = g.hh + 1;
+  g.KR = (g.nrow + 3) & ~3; g.NR = (g.nrow + 15) & ~15;
+  g.M1 = (g.ncol + 15) & ~15; g.Kc = (g.ncol + 3) & ~3;
+  g.N1 = (bh + 15) & ~15;
+  g.SX = a.lds_sx; g.ST = a.lds_st;
+  return g;
+}
 
-  // padded GEMM dimensions (host builds the tables with the same formulas)
-  const int KR = (nrow + 3) & ~3;          // stage-1 K  (ky <= hh)
-  const int NR = (nrow + 15) & ~15;        // stage-1 N  (y  <= hh)
-  const int M1 = (ncol + 15) & ~15;        // stage-1 M  (kx)  = stage-2 N (x <= hw)
-  const int Kc = (ncol + 3) & ~3;          // stage-2 K per half (re | im rows of T^T)
-  const int N1 = (bh + 15) & ~15;          // stage-2 M  (y)
-
-  if (TABLDS) {
-    // DFT operand tables of this block shape: global -> LDS by LDS-DMA (no registers), in flight during the
-    // coefficient phase; whole 1 KiB pieces (128 doubles: the table sizes are multiples of 128 doubles), piece c by
-    // wave c mod NW.  The barrier after the coefficient phase drains them.
-    const int wv = wave;
-    const double* gA = a.tables + sc.fy_off;
-    for (int c = wv; c < (2 * KR * NR) / 128; c += NW)
-      __builtin_amdgcn_global_load_lds(gA + c * 128 + 2 * lane, (__attribute__((address_space(3))) void*)(tabA + c * 128), 16, 0, 0);
-    const double* gG = a.tables + sc.g_off;
-    for (int c = wv; c < (2 * Kc * M1) / 128; c += NW)
-      __builtin_amdgcn_global_load_lds(gG + c * 128 + 2 * lane, (__attribute__((address_space(3))) void*)(tabG + c * 128), 16, 0, 0);
-  }
-
-  // ---- folded Hermitian half-plane coefficients -> LDS -------------------------------------------
-  // one work item per (ky <= hh, kx): rows ky and bh-ky share the spectral amplitude, and on the two self-conjugate
-  // columns they are a conjugate pair built from the same two draws.
-  {
-    const int npad = KR * M1;
-    const uint32_t m_m1 = pmagic((uint32_t)M1);
-    for (int i = tid; i < npad; i += NT) {
+// ---- folded Hermitian half-plane coefficients ------------------------------------------------------
+// One work item per (ky <= hh, kx <= hw): rows ky and bh-ky share the spectral amplitude, and on the two self-conjugate
+// columns they are a conjugate pair built from the same two draws.  Thread t of NTH handles items i_lo + t, + NTH, ... below
+// i_hi, and -- if `pad` -- the zero padding of the [KR][M1] operand grid.  The four planes may live in LDS or in global
+// memory (plane stride `plane`, row stride SX).
+template <int NTH, bool NOISE_IN>
+__device__ __forceinline__ void coef_items(const int t, const int i_lo, const int i_hi, const bool pad, const ProposeArgs& a,
+                                           const PropScalars& sc, const PropGeom& g, const uint64_t seed, const int64_t step,
+                                           double* __restrict__ Pr, const int plane, const NoiseIn noise) {
+  const gsm_rf_params& P = a.rf;
+  double* __restrict__ Pi = Pr + plane;
+  double* __restrict__ Mr = Pi + plane;
+  double* __restrict__ Mi = Mr + plane;
+  const int SX = g.SX, bh = g.bh, bw = g.bw, hh = g.hh, hw = g.hw, ncol = g.ncol, nrow = g.nrow;
+  if (pad) {
+    const int npad = g.KR * g.M1;
+    const uint32_t m_m1 = pmagic((uint32_t)g.M1);
+    for (int i = t; i < npad; i += NTH) {
       const int ky = (int)__umulhi((uint32_t)i, m_m1);
-      const int kx = i - ky * M1;
+      const int kx = i - ky * g.M1;
       if (ky >= nrow || kx >= ncol) {
         const int o = ky * SX + kx;
         Pr[o] = 0.0; Pi[o] = 0.0; Mr[o] = 0.0; Mi[o] = 0.0;
       }
     }
-    const int nitem = nrow * ncol;
-    const double inv_x = 1.0 / ((double)bw * P.resolution), inv_y = 1.0 / ((double)bh * P.resolution);
-    const uint32_t m_nc = pmagic((uint32_t)ncol);
-    for (int i = tid; i < nitem && !(a.dbg & 32); i += NT) {
-      const int ky = (int)__umulhi((uint32_t)i, m_nc);
-      const int kx = i - ky * ncol;
-      const int kyc = bh - ky;
-      const bool paired = (ky != 0) && (ky != hh);
-      double amp, g1 = 0.0, g2 = 0.0, h1 = 0.0, h2 = 0.0;
-      double ar, ai, br = 0.0, bi = 0.0;   // X[ky], X[bh - ky]
-      if (NOISE_IN) {
-        amp = spectral_amp(P, sc, ky, kx, bh, bw, inv_x, inv_y);
-        const int nky = (ky == 0) ? 0 : kyc, nkx = (kx == 0) ? 0 : bw - kx;      // -k modulo the block shape
-        ar = amp * (0.5 * (noise.re[ky * bw + kx] + noise.re[nky * bw + nkx]));
-        ai = amp * (0.5 * (noise.im[ky * bw + kx] - noise.im[nky * bw + nkx]));
-        if (paired) {                                                            // row bh - ky; its partner row is ky
-          br = amp * (0.5 * (noise.re[kyc * bw + kx] + noise.re[ky * bw + nkx]));
-          bi = amp * (0.5 * (noise.im[kyc * bw + kx] - noise.im[ky * bw + nkx]));
-        }
-      } else {
+  }
+  const double inv_x = 1.0 / ((double)bw * P.resolution), inv_y = 1.0 / ((double)bh * P.resolution);
+  const uint32_t m_nc = pmagic((uint32_t)ncol);
+  for (int i = i_lo + t; i < i_hi && !(a.dbg & 32); i += NTH) {
+    const int ky = (int)__umulhi((uint32_t)i, m_nc);
+    const int kx = i - ky * ncol;
+    const int kyc = bh - ky;
+    const bool paired = (ky != 0) && (ky != hh);
+    double amp, g1 = 0.0, g2 = 0.0, h1 = 0.0, h2 = 0.0;
+    double ar, ai, br = 0.0, bi = 0.0;   // X[ky], X[bh - ky]
+    if (NOISE_IN) {
+      amp = spectral_amp(P, sc, ky, kx, bh, bw, inv_x, inv_y);
+      const int nky = (ky == 0) ? 0 : kyc, nkx = (kx == 0) ? 0 : bw - kx;      // -k modulo the block shape
+      ar = amp * (0.5 * (noise.re[ky * bw + kx] + noise.re[nky * bw + nkx]));
+      ai = amp * (0.5 * (noise.im[ky * bw + kx] - noise.im[nky * bw + nkx]));
+      if (paired) {                                                            // row bh - ky; its partner row is ky
+        br = amp * (0.5 * (noise.re[kyc * bw + kx] + noise.re[ky * bw + nkx]));
+        bi = amp * (0.5 * (noise.im[kyc * bw + kx] - noise.im[ky * bw + nkx]));
+      }
+    } else {
       if (a.dbg & 1) { amp = 1.0; g1 = ky; g2 = kx; h1 = 1.0; h2 = 2.0; }
       else {
         amp = spectral_amp(P, sc, ky, kx, bh, bw, inv_x, inv_y);
@@ -247,75 +217,79 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
       } else {
         ar = amp * (0.5 * (g1 + g1)); ai = amp * (0.5 * (g2 - g2));
       }
-      }
-      const int o = ky * SX + kx;
-      Pr[o] = ar + br; Pi[o] = ai + bi;
-      Mr[o] = paired ? ar - br : 0.0;
-      Mi[o] = paired ? ai - bi : 0.0;
     }
+    const int o = ky * SX + kx;
+    Pr[o] = ar + br; Pi[o] = ai + bi;
+    Mr[o] = paired ? ar - br : 0.0;
+    Mi[o] = paired ? ai - bi : 0.0;
   }
-  after_coeff();
-  PSTAMP(10);
-  if (TABLDS) {
-    // The table LDS-DMAs are older than the HOOK_VMEM vector-memory instructions the hook has just issued: wait for
-    // everything but those (vmcnt counts in order), and for this wave's LDS writes; then a bare barrier.
-    // __syncthreads() would wait vmcnt(0) here, i.e. for the hook's HBM loads.
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(HOOK_VMEM) : "memory");
-  } else {
-    __syncthreads();
-  }
-  PSTAMP(11);
-  // Mean of the field (MCMC.py:248 subtracts it): every non-DC term of the inverse DFT sums to zero over the block, so
-  // mean = X[0][0] / (bh bw) with X[0][0] = Pr[0] (real: its own conjugate partner).  Read before T^T overlays the plane.
-  const double dc = Pr[0];
+}
 
+// DFT operand tables of this block shape: global -> LDS by LDS-DMA (no registers); whole 1 KiB pieces (128 doubles: the
+// table sizes are multiples of 128 doubles), piece c by wave c mod NW of the NW issuing waves.  AUX: cache policy bits.
+template <int NW, int AUX = 0>
+__device__ __forceinline__ void dma_to_lds(const double* __restrict__ src, double* dst, const int n_doubles, const int w, const int lane) {
+  for (int c = w; c < n_doubles / 128; c += NW)
+    __builtin_amdgcn_global_load_lds(src + c * 128 + 2 * lane, (__attribute__((address_space(3))) void*)(dst + c * 128), 16, 0, AUX);
+}
+
+// ---- stage 1 (MFMA): U = P^T C, V = M^T S on ky, y in [0, hh] -----------------------------------
+// Work unit = half an output tile: half 0 accumulates (Ur, Vi) = (Pr C, Mi S), which is all the real part of T^T
+// needs; half 1 accumulates (Ui, Vr) = (Pi C, Mr S) for the imaginary part.  Unit u goes to wave u mod NW.  Results wait
+// in registers until every wave has finished reading the planes, then overwrite them as T^T (tt_write).
+template <int NW, int UPW, bool TABLDS>
+__device__ __forceinline__ void dft_stage1(const int w, const int lane, const ProposeArgs& a, const PropScalars& sc, const PropGeom& g,
+                                           const double* plds, const double* tabA, v4f64 (&uc)[UPW], v4f64 (&us)[UPW]) {
+  const int SX = g.SX, KR = g.KR, NR = g.NR;
+  const double* Pr = plds;
+  const double* Pi = Pr + a.lds_x_half;
+  const double* Mr = Pi + a.lds_x_half;
+  const double* Mi = Mr + a.lds_x_half;
   const int l15 = lane & 15, l4 = lane >> 4;
-
-  // ---- stage 1 (MFMA): U = P^T C, V = M^T S on ky, y in [0, hh] -----------------------------------
-  // Work unit = half an output tile: half 0 accumulates (Ur, Vi) = (Pr C, Mi S), which is all the real part of T^T
-  // needs; half 1 accumulates (Ui, Vr) = (Pi C, Mr S) for the imaginary part.  Unit u goes to wave u mod NW, so the
-  // (up to 18) units spread over all waves and SIMDs.  Results wait in registers until every wave has finished reading
-  // the planes, then overwrite them as T^T.
-  constexpr int UPW = 32 / NW;                 // units per wave: 2 halves x (at most 16 tiles) / NW
-  v4f64 uc[UPW], us[UPW];                      // cos-product and sin-product accumulators of the unit
-  const int n_mt = M1 >> 4, n_nt = NR >> 4;
+  const int n_mt = g.M1 >> 4, n_nt = NR >> 4;
   const int n_t1 = n_mt * n_nt;
-  {
-    const double* __restrict__ FC = a.tables + sc.fy_off;      // [KR][NR]
-    const double* __restrict__ FS = FC + KR * NR;
-#pragma unroll
-    for (int j = 0; j < UPW; ++j) {
-      v4f64 ac = {0.0, 0.0, 0.0, 0.0}, as = ac;
-      const int u = wave + j * NW;
-      const int t = u >> 1;
-      if (t < n_t1 && !(a.dbg & 2)) {
-        const int mt = t % n_mt, nt = t / n_mt;
-        const int ao = l4 * SX + 16 * mt + l15;
-        const double* __restrict__ Ac = (u & 1) ? Pi : Pr;
-        const double* __restrict__ As = (u & 1) ? Mr : Mi;
-        const double* fc_p = FC + l4 * NR + 16 * nt + l15;
-        const double* fs_p = FS + l4 * NR + 16 * nt + l15;
-#pragma unroll 2
-        for (int k0 = 0; k0 < KR; k0 += 4) {
-          double bc, bs;
-          if (TABLDS) {
-            const int bo = (l4 + k0) * NR + 16 * nt + l15;
-            bc = tabA[bo]; bs = tabA[KR * NR + bo];
-          } else {
-            bc = fc_p[k0 * NR]; bs = fs_p[k0 * NR];
-          }
-          const int o = ao + k0 * SX;
-          ac = __builtin_amdgcn_mfma_f64_16x16x4f64(Ac[o], bc, ac, 0, 0, 0);
-          as = __builtin_amdgcn_mfma_f64_16x16x4f64(As[o], bs, as, 0, 0, 0);
-        }
-      }
-      uc[j] = ac; us[j] = as;
-    }
-  }
-  __syncthreads();
+  const double* __restrict__ FC = a.tables + sc.fy_off;      // [KR][NR]
+  const double* __restrict__ FS = FC + KR * NR;
 #pragma unroll
   for (int j = 0; j < UPW; ++j) {
-    const int u = wave + j * NW;
+    v4f64 ac = {0.0, 0.0, 0.0, 0.0}, as = ac;
+    const int u = w + j * NW;
+    const int t = u >> 1;
+    if (t < n_t1 && !(a.dbg & 2)) {
+      const int mt = t % n_mt, nt = t / n_mt;
+      const int ao = l4 * SX + 16 * mt + l15;
+      const double* __restrict__ Ac = (u & 1) ? Pi : Pr;
+      const double* __restrict__ As = (u & 1) ? Mr : Mi;
+      const double* fc_p = FC + l4 * NR + 16 * nt + l15;
+      const double* fs_p = FS + l4 * NR + 16 * nt + l15;
+#pragma unroll 2
+      for (int k0 = 0; k0 < KR; k0 += 4) {
+        double bc, bs;
+        if (TABLDS) {
+          const int bo = (l4 + k0) * NR + 16 * nt + l15;
+          bc = tabA[bo]; bs = tabA[KR * NR + bo];
+        } else {
+          bc = fc_p[k0 * NR]; bs = fs_p[k0 * NR];
+        }
+        const int o = ao + k0 * SX;
+        ac = __builtin_amdgcn_mfma_f64_16x16x4f64(Ac[o], bc, ac, 0, 0, 0);
+        as = __builtin_amdgcn_mfma_f64_16x16x4f64(As[o], bs, as, 0, 0, 0);
+      }
+    }
+    uc[j] = ac; us[j] = as;
+  }
+}
+
+template <int NW, int UPW>
+__device__ __forceinline__ void dft_tt_write(const int w, const int lane, const PropGeom& g, double* TT, const v4f64 (&uc)[UPW],
+                                             const v4f64 (&us)[UPW]) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int n_mt = g.M1 >> 4, n_nt = g.NR >> 4;
+  const int n_t1 = n_mt * n_nt;
+  const int ST = g.ST, Kc = g.Kc, hh = g.hh, bh = g.bh;
+#pragma unroll
+  for (int j = 0; j < UPW; ++j) {
+    const int u = w + j * NW;
     const int t = u >> 1;
     if (t < n_t1) {
       const int mt = t % n_mt, nt = t / n_mt;
@@ -333,110 +307,147 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
       }
     }
   }
-  __syncthreads();
+}
 
-  PSTAMP(12);
-  // ---- stage 2 (MFMA): E = Tr^T Gc, O = Ti^T Gs on x in [0, hw]; results stay in registers -----------
-  v4f64 fe[MAXT], fo[MAXT];
-  const int n_mt2 = N1 >> 4, n_nt2 = M1 >> 4;
+// ---- stage 2 (MFMA): E = Tr^T Gc, O = Ti^T Gs on x in [0, hw]; results stay in registers -----------
+// tile t of the (N1/16) x (M1/16) output grid goes to wave t mod NW
+template <int NW, int MAXT, bool TABLDS>
+__device__ __forceinline__ void dft_stage2(const int w, const int lane, const ProposeArgs& a, const PropScalars& sc, const PropGeom& g,
+                                           const double* TT, const double* tabG, v4f64 (&fe)[MAXT], v4f64 (&fo)[MAXT]) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int ST = g.ST, Kc = g.Kc, M1 = g.M1;
+  const int n_mt2 = g.N1 >> 4, n_nt2 = M1 >> 4;
   const int n_t2 = n_mt2 * n_nt2;
-  {
-    const double* __restrict__ GC = a.tables + sc.g_off;       // [Kc][M1]
-    const double* __restrict__ GS = GC + Kc * M1;
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-      v4f64 ae = {0.0, 0.0, 0.0, 0.0}, ao = ae;
-      const int t = wave + j * NW;
-      if (t < n_t2 && !(a.dbg & 4)) {
-        const int mt = t % n_mt2, nt = t / n_mt2;
-        const double* a_p = TT + l4 * ST + 16 * mt + l15;
-        const double* gc_p = GC + l4 * M1 + 16 * nt + l15;
-        const double* gs_p = GS + l4 * M1 + 16 * nt + l15;
-#pragma unroll 2
-        for (int k0 = 0; k0 < Kc; k0 += 4) {
-          double gc, gs;
-          if (TABLDS) {
-            const int bo = (l4 + k0) * M1 + 16 * nt + l15;
-            gc = tabG[bo]; gs = tabG[Kc * M1 + bo];
-          } else {
-            gc = gc_p[k0 * M1]; gs = gs_p[k0 * M1];
-          }
-          ae = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p[k0 * ST], gc, ae, 0, 0, 0);
-          ao = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p[(Kc + k0) * ST], gs, ao, 0, 0, 0);
-        }
-      }
-      fe[j] = ae; fo[j] = ao;
-    }
-  }
-
-  PSTAMP(13);
-  double mreg[MAXT][8];   // TABLDS: edge-mask values of the thread's cells, in flight during stage 2 and the reductions
-  if (TABLDS) {
-    const dev::rsrc_t r_mask = dev::make_rsrc(a.B.masks + sc.mask_off, (uint32_t)(bh * bw) * 8u);
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-      const int t = wave + j * NW;
-      const int mt = t % n_mt2, nt = t / n_mt2;
-      const int x = 16 * nt + l15;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int y = 16 * mt + l4 + 4 * q;
-        const bool ok = (t < n_t2) && (y < bh) && (x <= hw);
-        mreg[j][2 * q] = dev::ld_f64<0>(r_mask, ok ? (uint32_t)(y * bw + x) * 8u : dev::kOOB);
-        mreg[j][2 * q + 1] = dev::ld_f64<0>(r_mask, (ok && x > 0 && x < hw) ? (uint32_t)(y * bw + bw - x) * 8u : dev::kOOB);
-      }
-    }
-  }
-  // ---- standardise (MCMC.py:248) on the register-resident field ---------------------------------
-  // lane holds, per (tile j, reg q): v1 = field[y][x] = E + O and, for 0 < x < hw, v2 = field[y][bw - x] = E - O
-  const int ncell = bh * bw;
-  const double inv_n = 1.0 / (double)ncell;
-  double part[MAXT];
+  const double* __restrict__ GC = a.tables + sc.g_off;       // [Kc][M1]
+  const double* __restrict__ GS = GC + Kc * M1;
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
-    const int t = wave + j * NW;
+    v4f64 ae = {0.0, 0.0, 0.0, 0.0}, ao = ae;
+    const int t = w + j * NW;
+    if (t < n_t2 && !(a.dbg & 4)) {
+      const int mt = t % n_mt2, nt = t / n_mt2;
+      const double* a_p = TT + l4 * ST + 16 * mt + l15;
+      const double* gc_p = GC + l4 * M1 + 16 * nt + l15;
+      const double* gs_p = GS + l4 * M1 + 16 * nt + l15;
+#pragma unroll 2
+      for (int k0 = 0; k0 < Kc; k0 += 4) {
+        double gc, gs;
+        if (TABLDS) {
+          const int bo = (l4 + k0) * M1 + 16 * nt + l15;
+          gc = tabG[bo]; gs = tabG[Kc * M1 + bo];
+        } else {
+          gc = gc_p[k0 * M1]; gs = gs_p[k0 * M1];
+        }
+        ae = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p[k0 * ST], gc, ae, 0, 0, 0);
+        ao = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p[(Kc + k0) * ST], gs, ao, 0, 0, 0);
+      }
+    }
+    fe[j] = ae; fo[j] = ao;
+  }
+}
+
+// edge-mask values of the wave's cells (TABLDS form: issued early, in flight during stage 2 and the reductions)
+template <int NW, int MAXT>
+__device__ __forceinline__ void mask_prefetch(const int w, const int lane, const ProposeArgs& a, const PropScalars& sc, const PropGeom& g,
+                                              double (&mreg)[MAXT][8]) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int bh = g.bh, bw = g.bw, hw = g.hw;
+  const int n_mt2 = g.N1 >> 4, n_t2 = n_mt2 * (g.M1 >> 4);
+  const dev::rsrc_t r_mask = dev::make_rsrc(a.B.masks + sc.mask_off, (uint32_t)(bh * bw) * 8u);
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int t = w + j * NW;
     const int mt = t % n_mt2, nt = t / n_mt2;
     const int x = 16 * nt + l15;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int y = 16 * mt + l4 + 4 * q;
       const bool ok = (t < n_t2) && (y < bh) && (x <= hw);
-      const bool two = ok && (x > 0) && (x < hw);
-      const double e = fe[j][q], o = fo[j][q];
-      const double v1 = ok ? (e + o) * inv_n : 0.0;
-      const double v2 = two ? (e - o) * inv_n : 0.0;
-      fe[j][q] = v1; fo[j][q] = v2;
+      mreg[j][2 * q] = dev::ld_f64<0>(r_mask, ok ? (uint32_t)(y * bw + x) * 8u : dev::kOOB);
+      mreg[j][2 * q + 1] = dev::ld_f64<0>(r_mask, (ok && x > 0 && x < hw) ? (uint32_t)(y * bw + bw - x) * 8u : dev::kOOB);
     }
   }
-  const double mean = dc * inv_n;
+}
+
+// Sum over the workgroup of per-tile partials: tile t is reduced by the wave that owns it (fixed lane order, DPP),
+// then the 16 tile slots are added by a fixed DPP tree in every thread.  red: 16 doubles of LDS, not reused before the
+// next barrier.  Every thread of the workgroup must call it (it contains the barrier); waves that own no tile pass w < 0
+// and write nothing.  All 16 slots must be written: slot t by its owner, or by wave 0 of the owners if t >= n_tiles...
+template <int NW, int MAXT>
+__device__ __forceinline__ double tiles_sum(const double (&part)[MAXT], const int n_tiles, double* red, const int w, const int lane) {
+  static_assert(NW * MAXT >= 16, "the 16 tile slots must all have an owner");
+  if (w >= 0) {
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const double ws = dev::wave64_sum(part[j]);
+      const int t = w + j * NW;
+      if (lane == 0 && t < 16) red[t] = (t < n_tiles) ? ws : 0.0;   // all 16 slots are written
+    }
+  }
+  // only LDS traffic has to be complete here: a bare barrier leaves the caller's global loads in flight
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  return dev::row16_sum(red[lane & 15]);   // fixed tree over the 16 tile slots: the same value in every lane
+}
+
+// ---- standardise (MCMC.py:248) on the register-resident field -------------------------------------
+// lane holds, per (tile j, reg q): v1 = field[y][x] = E + O and, for 0 < x < hw, v2 = field[y][bw - x] = E - O.
+// On return fe / fo hold v1 / v2 (scaled by 1 / n) and the function value is the gain (scale / (sd + 1e-12)); `mean` out.
+template <int NW, int MAXT>
+__device__ __forceinline__ double standardise(const int w, const int lane, const PropScalars& sc, const PropGeom& g, const double dc,
+                                              double* red, v4f64 (&fe)[MAXT], v4f64 (&fo)[MAXT], double& mean) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int bh = g.bh, hw = g.hw;
+  const int n_mt2 = g.N1 >> 4, n_t2 = n_mt2 * (g.M1 >> 4);
+  const int ncell = bh * g.bw;
+  const double inv_n = 1.0 / (double)ncell;
+  double part[MAXT];
+  mean = dc * inv_n;
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
-    const int t = wave + j * NW;
+    const int t = w + j * NW;
     const int mt = t % n_mt2, nt = t / n_mt2;
     const int x = 16 * nt + l15;
     double p = 0.0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int y = 16 * mt + l4 + 4 * q;
-      const bool ok = (t < n_t2) && (y < bh) && (x <= hw);
+      const bool ok = (w >= 0) && (t < n_t2) && (y < bh) && (x <= hw);
+      const bool two = ok && (x > 0) && (x < hw);
+      const double e = fe[j][q], o = fo[j][q];
+      const double v1 = ok ? (e + o) * inv_n : 0.0;
+      const double v2 = two ? (e - o) * inv_n : 0.0;
+      fe[j][q] = v1; fo[j][q] = v2;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int y = 16 * mt + l4 + 4 * q;
+      const bool ok = (w >= 0) && (t < n_t2) && (y < bh) && (x <= hw);
       if (ok) { const double d = fe[j][q] - mean; p += d * d; }
       if (ok && x > 0 && x < hw) { const double d = fo[j][q] - mean; p += d * d; }
     }
     part[j] = p;
   }
-  const double sd = sqrt(tiles_sum<NT>(part, n_t2, red, tid) * inv_n);
-  const double gain = sc.scale / (sd + 1e-12);
+  const double sd = sqrt(tiles_sum<NW, MAXT>(part, n_t2, red, w, lane) * inv_n);
+  return sc.scale / (sd + 1e-12);
+}
 
-  PSTAMP(14);
-  // ---- scale, nugget (MCMC.py:251), edge mask (MCMC.py:778), store ------------------------------
-  // out = (t + n * sqrt(nug)) * mask with t = (field - mean) * gain.  Without a nugget (nugget_max == 0: n * 0 adds
-  // nothing) the finished value is stored directly; with one, t is stored first and a second pass over cell pairs adds
-  // the nugget normals (one Philox block per pair) and applies the mask -- the same operations in the same order.
+// ---- scale, nugget (MCMC.py:251), edge mask (MCMC.py:778), store ------------------------------
+// out = (t + n * sqrt(nug)) * mask with t = (field - mean) * gain.  Without a nugget the finished value is stored
+// directly; with one, t is stored first and nugget_pass adds the nugget normals and applies the mask -- the same
+// operations in the same order.  Cell (y, x) goes to out[omap(y, x)], or nowhere if omap returns a negative index.
+template <int NW, int MAXT, bool TABLDS, class OMap>
+__device__ __forceinline__ void emit_field(const int w, const int lane, const ProposeArgs& a, const PropScalars& sc, const PropGeom& g,
+                                           const v4f64 (&fe)[MAXT], const v4f64 (&fo)[MAXT], const double (&mreg)[MAXT][8],
+                                           const double mean, const double gain, const bool with_nugget,
+                                           double* __restrict__ out, OMap omap) {
+  if (w < 0) return;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int bh = g.bh, bw = g.bw, hw = g.hw;
+  const int n_mt2 = g.N1 >> 4, n_t2 = n_mt2 * (g.M1 >> 4);
   const double* __restrict__ mask = a.B.masks + sc.mask_off;
-  const bool with_nugget = NOISE_IN ? (noise.nug != nullptr) : (P.nugget_max > 0.0);
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
-    const int t = wave + j * NW;
+    const int t = w + j * NW;
     const int mt = t % n_mt2, nt = t / n_mt2;
     const int x = 16 * nt + l15;
 #pragma unroll
@@ -455,22 +466,62 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
       }
     }
   }
-  if (with_nugget) {
-    const double sq_nug = sqrt(sc.nug);
-    __syncthreads();
-    for (int pr = tid; 2 * pr < ncell; pr += NT) {
-      double n1, n2;
-      const int o = 2 * pr;
-      if (NOISE_IN) { n1 = noise.nug[o]; n2 = noise.nug[o + 1]; }
-      else {
-        normals2(seed, step, kStreamNugget, (uint32_t)pr, n1, n2);
-        n1 *= sq_nug; n2 *= sq_nug;
-      }
-      const int y = o / bw, x = o - y * bw;       // bw is even: the pair (o, o + 1) lies in one row
-      const int o0 = omap(y, x), o1 = omap(y, x + 1);
-      if (o0 >= 0) out[o0] = (out[o0] + n1) * mask[o];
-      if (o1 >= 0) out[o1] = (out[o1] + n2) * mask[o + 1];
+}
+
+// second pass of the nugget case over cell pairs, by NTH threads (thread index t); call after a workgroup barrier
+template <int NTH, bool NOISE_IN, class OMap>
+__device__ __forceinline__ void nugget_pass(const int t, const ProposeArgs& a, const PropScalars& sc, const PropGeom& g,
+                                            const uint64_t seed, const int64_t step, const NoiseIn noise,
+                                            double* __restrict__ out, OMap omap) {
+  const double* __restrict__ mask = a.B.masks + sc.mask_off;
+  const int bw = g.bw, ncell = g.bh * g.bw;
+  const double sq_nug = sqrt(sc.nug);
+  for (int pr = t; 2 * pr < ncell; pr += NTH) {
+    double n1, n2;
+    const int o = 2 * pr;
+    if (NOISE_IN) { n1 = noise.nug[o]; n2 = noise.nug[o + 1]; }
+    else {
+      normals2(seed, step, kStreamNugget, (uint32_t)pr, n1, n2);
+      n1 *= sq_nug; n2 *= sq_nug;
     }
+    const int y = o / bw, x = o - y * bw;       // bw is even: the pair (o, o + 1) lies in one row
+    const int o0 = omap(y, x), o1 = omap(y, x + 1);
+    if (o0 >= 0) out[o0] = (out[o0] + n1) * mask[o];
+    if (o1 >= 0) out[o1] = (out[o1] + n2) * mask[o + 1];
+  }
+}
+
+// ---- all stages in turn, by all NT threads of the workgroup (stand-alone kernels) ------------------------------------
+// plds: LDS work area of a.lds_main doubles; red: 32 doubles of LDS.  Contains workgroup barriers: every thread must call
+// it with the same (uniform) arguments.  On return other waves may still be reading `red`.
+template <int NT, bool NOISE_IN = false, class OMap>
+__device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& a, const PropScalars& sc, const uint64_t seed,
+                                              const int64_t step, double* plds, double* red, double* __restrict__ out, OMap omap,
+                                              const NoiseIn noise = NoiseIn{nullptr, nullptr, nullptr}) {
+  constexpr int NW = NT / 64, MAXT = 16 / NW, UPW = 32 / NW;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const PropGeom g = prop_geom(a, sc.bh, sc.bw);
+  coef_items<NT, NOISE_IN>(tid, 0, g.nrow * g.ncol, true, a, sc, g, seed, step, plds, a.lds_x_half, noise);
+  __syncthreads();
+  // Mean of the field (MCMC.py:248 subtracts it): every non-DC term of the inverse DFT sums to zero over the block, so
+  // mean = X[0][0] / (bh bw) with X[0][0] = Pr[0] (real: its own conjugate partner).  Read before T^T overlays the plane.
+  const double dc = plds[0];
+  v4f64 uc[UPW], us[UPW];
+  dft_stage1<NW, UPW, false>(wave, lane, a, sc, g, plds, nullptr, uc, us);
+  __syncthreads();
+  dft_tt_write<NW, UPW>(wave, lane, g, plds, uc, us);
+  __syncthreads();
+  v4f64 fe[MAXT], fo[MAXT];
+  dft_stage2<NW, MAXT, false>(wave, lane, a, sc, g, plds, nullptr, fe, fo);
+  double mreg[MAXT][8];
+  double mean;
+  const double gain = standardise<NW, MAXT>(wave, lane, sc, g, dc, red, fe, fo, mean);
+  const bool with_nugget = NOISE_IN ? (noise.nug != nullptr) : (a.rf.nugget_max > 0.0);
+  emit_field<NW, MAXT, false>(wave, lane, a, sc, g, fe, fo, mreg, mean, gain, with_nugget, out, omap);
+  if (with_nugget) {
+    __syncthreads();
+    nugget_pass<NT, NOISE_IN>(tid, a, sc, g, seed, step, noise, out, omap);
   }
 }
 

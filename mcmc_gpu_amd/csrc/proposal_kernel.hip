@@ -109,8 +109,8 @@ __global__ __launch_bounds__(NT, NT / 256) void propose_kernel(const ProposeArgs
   const PropScalars sc = a.scalars[rec];
   if (a.dbg & 64) { if (threadIdx.x == 0) a.fields[rec * a.field_stride] = (double)sc.bh; return; }
   double* __restrict__ out = a.fields + rec * a.field_stride;
-  propose_field<NT, false, 0>((int)threadIdx.x, a, sc, a.seeds[chain], a.step0 + s, plds, red, nullptr, nullptr, [] {}, out,
-                              [bw = sc.bw](int y, int x) { return y * bw + x; });
+  propose_field<NT>((int)threadIdx.x, a, sc, a.seeds[chain], a.step0 + s, plds, red, out,
+                    [bw = sc.bw](int y, int x) { return y * bw + x; });
 }
 
 // gsm_spectral_from_noise: scalar records from caller-supplied (size index, scale, nugget, ranges) ...
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(512, 2) void spectral_from_noise_kernel(const Propo
   const PropScalars sc = a.scalars[rec];
   const NoiseIn nz{noise_re + rec * a.field_stride, noise_im + rec * a.field_stride,
                    nugget_field ? nugget_field + rec * a.field_stride : nullptr};
-  propose_field<512, false, 0, true>((int)threadIdx.x, a, sc, 0, 0, plds, red, nullptr, nullptr, [] {},
-                                     a.fields + rec * a.field_stride, [bw = sc.bw](int y, int x) { return y * bw + x; }, nz);
+  propose_field<512, true>((int)threadIdx.x, a, sc, 0, 0, plds, red, a.fields + rec * a.field_stride,
+                           [bw = sc.bw](int y, int x) { return y * bw + x; }, nz);
 }
 
 hipError_t launch_spectral_from_noise(const ProposeArgs& a, const int32_t* size_idx, const double* rf_scalars,

@@ -25,11 +25,13 @@ out = np.zeros((a.chains, 16), dtype=np.uint64)
 eng.lib.gsm_debug_stamps_fused.argtypes = [C.c_void_p, C.c_int32]
 rc = eng.lib.gsm_debug_stamps_fused(out.ctypes.data, a.chains)
 assert rc == 0, rc
-names = {15: "loop top", 0: "scalars+window+fence", 1: "P0 issue state loads", 10: "P coefficients (Philox, BM, amp)", 11: "P barrier",
-         12: "P stage 1 MFMA + T^T", 13: "P stage 2 MFMA", 14: "P standardise (2 sums)", 2: "P scale+mask -> LDS", 3: "P->A barrier",
-         4: "A statics+flux", 5: "A barrier", 6: "D stencil", 7: "R wave-reduce", 8: "R barrier", 9: "decide+E commit"}
+names = {15: "loop top", 0: "window + fence", 2: "P0 state loads + barrier A (DMA wait)", 1: "S1: stage 1 MFMA (wave 0)",
+         13: "S1 barrier (waits for coefficient waves)", 10: "T^T write + barrier", 11: "S2: stage 2 MFMA + mask loads",
+         14: "standardise (reduction + barrier)", 12: "emit -> LDS", 3: "emit barrier", 4: "A statics+flux", 5: "A barrier",
+         6: "D stencil", 7: "R wave-reduce", 8: "R barrier", 9: "DMA issue + decide + E commit"}
+order = [15, 0, 2, 1, 13, 10, 11, 14, 12, 3, 4, 5, 6, 7, 8, 9]
 per = out.astype(np.float64).mean(axis=0) / a.steps
 print(f"fused launch {tm['step_ms']:.3f} ms for {a.steps} steps x {a.chains} chains; accept {np.mean(acc):.3f}")
-for k in [15, 0, 1, 10, 11, 12, 13, 14, 2, 3, 4, 5, 6, 7, 8, 9]:
+for k in order:
     print(f"  {names[k]:34s} {per[k]:9.0f} cycles/step  ({100 * per[k] / per.sum():5.1f} %)")
 print(f"  total                              {per.sum():9.0f} cycles/step")
