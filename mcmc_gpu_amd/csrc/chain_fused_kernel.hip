@@ -5,25 +5,18 @@
 // Only the chain state touches HBM: read bed (window + halo) and carried energy (window); on accept write both back
 // and bump resampled_times -- the algorithmic traffic of SURVEY.md section 8d plus the halo ring.
 //
-// Wave roles.  On gfx950 the fp64 matrix pipe and the fp64 vector pipe have the same peak rate and run side by side, but a
-// workgroup that walks through the proposal phase by phase uses them one after the other.  The proposal of step s + 1 does
-// not depend on the chain's state (counter-based draws), so the workgroup is split for the two matrix-core stages:
-//   waves 4..15 (3 per SIMD)  the inverse-DFT stages of step s on the matrix cores (operands from LDS)
-//   waves 0..3  (1 per SIMD)  Philox + Box-Muller + spectral amplitude of step s + 1 on the vector pipe; the folded
-//                             coefficients go to a per-chain 68 KiB scratch in global memory (L2 resident).  They are the
-//                             oldest wave of their SIMD and raise their priority: VALU issue goes to them first
-// and the scratch is copied into the LDS coefficient planes by LDS-DMA (no registers) once the flux tiles that overlay
-// them are dead (after phase D of step s), flying under the reduction / commit phases.  Every other phase uses all 16 waves.
-//
 // Per step:
-//   P0  issue the loads of the bed / energy of the window into registers (HBM latency runs under the proposal)
-//   S1  stage 1 of the inverse DFT (12 waves)  ||  coefficients of step s+1, first two thirds (4 waves)
-//   S2  stage 2 (one output tile per wave)      ||  coefficients of step s+1, rest (4 waves, before their tile if any)
-//   std standardise, scale x edge mask -> LDS field tile
+//   P   proposal: DFT tables by LDS-DMA; Philox + Box-Muller + spectral amplitude -> folded coefficients in LDS planes
+//   P0  issue the loads of the bed / energy of the window into registers (HBM latency runs under the two MFMA stages;
+//       issued after the coefficient phase, whose Box-Muller code needs the registers)
+//   S1/S2 two fp64 MFMA inverse-DFT stages, standardise, scale x edge mask -> LDS field tile
 //   A   candidate bed = bed + f * weight (where update_mask), thickness guard, fluxes -> two LDS tiles (they overlay the
 //       proposal's planes), sum of the carried energy
-//   D   5-point stencil on the flux tiles -> new energies;  R  reduction + accept test;  then the LDS-DMA of the next
-//       step's coefficient planes and DFT tables is issued;  E  commit on accept
+//   D   5-point stencil on the flux tiles -> new energies;  R  reduction + accept test;  E  commit on accept
+// Measured and rejected (round 2): splitting the workgroup into matrix-core waves (DFT stages of step s)
+// and coefficient waves (Philox / Box-Muller of step s + 1, handed over through an L2-resident scratch and LDS-DMA).  On
+// gfx950 the fp64 MFMA and the fp64 vector FMA have the same peak and do not run side by side on one SIMD: the merged
+// interval took as long as the two phases one after the other.
 // LDS (80 x 80 blocks): flux tiles / DFT planes 105 KiB + field tile 50 KiB + scratch < 160 KiB.
 //
 // The arithmetic of a step is the same, operation for operation, as gsm_propose_philox followed by gsm_run_replay
@@ -40,17 +33,13 @@ namespace gsm {
 
 using namespace dev;
 
-constexpr int kNWC = 8;                  // coefficient waves: waves 0..7, the two OLDEST waves of each SIMD (VALU issue is arbitrated
-                                         // by priority, then age: MI355X_MICROARCH.md, 'Two waves per SIMD')
-constexpr int kNWM = kNW - kNWC;         // matrix-core waves of stage 1: waves 4..15
-constexpr int kNTV = kNWC * 64;          // threads of the coefficient waves
-constexpr int kUPW = 3;                   // stage-1 units per matrix-core wave (24 units = 12 output tiles)
+constexpr int kUPW = 32 / kNW;             // stage-1 units per wave (2 halves x at most 16 output tiles over 16 waves)
 
 #ifdef GSM_STAMPS
 // diagnostic build only (GSM_STAMPS=1 at build time): per-workgroup cycle totals of the phases, thread 0
 __device__ unsigned long long g_stamps_fused[4096 * 16];
 #ifndef GSM_STAMP_TID
-#define GSM_STAMP_TID 512    // first lane of the first matrix-core wave; 0: first coefficient wave
+#define GSM_STAMP_TID 0
 #endif
 #define STAMP(slot) do { if (tid == GSM_STAMP_TID) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
     st_acc[slot] += t_ - st_last; st_last = t_; } } while (0)
@@ -163,17 +152,6 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     q.bh = r->bh; q.bw = r->bw; q.fy_off = r->fy_off; q.g_off = r->g_off; q.mask_off = r->mask_off;
     return q;
   };
-  {
-    // prologue: the coefficients of the launch's first step by all 16 waves straight into the LDS planes, its DFT tables by
-    // LDS-DMA; both are awaited at the first barrier of the step loop
-    const cargs_t K = kargs();
-    const ProposeArgs pa = load_c(&K->P);
-    const PropScalars q = prop_rec(rec_at(K, 0));
-    const PropGeom g0 = prop_geom(pa, q.bh, q.bw);
-    dma_to_lds<kNW, 0>(pa.tables + q.fy_off, lds + lds_xh4, 2 * g0.KR * g0.NR, wave, lane);
-    dma_to_lds<kNW, 0>(pa.tables + q.g_off, fld, 2 * g0.Kc * g0.M1, wave, lane);
-    coef_items<kNT, false>(tid, 0, g0.nrow * g0.ncol, true, pa, q, g0, seed, pa.step0, lds, pa.lds_x_half, no_noise);
-  }
   for (int s = 0; s < n_steps; ++s) {
     STAMP(15);
     // Geometry of the thread's tile cells t, t + 1024, ... by (magic) division; ptid is laundered per phase so that the
@@ -192,13 +170,25 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       inwin = valid && (unsigned)(lr - G.dr) < (unsigned)G.wh && (unsigned)(lc - G.dc) < (unsigned)G.ww;
     };
 
-    // ---- P0: chain state of the window -> registers --------------------------------------------------------------------
-    // The matrix-core waves request it now (the HBM latency runs under the two MFMA stages).  The coefficient waves request
-    // theirs when their items are done (it then flies under the standardisation): their item code needs the registers.
+    // ---- P: DFT tables -> LDS by LDS-DMA (in flight during the coefficient phase), folded coefficients -> LDS planes -----
+    {
+      const cargs_t K = kargs();
+      const ProposeArgs pa = load_c(&K->P);
+      const PropScalars q = prop_rec(rec_at(K, s));
+      const PropGeom pg = prop_geom(pa, q.bh, q.bw);
+      dma_to_lds<kNW, 0>(pa.tables + q.fy_off, lds + lds_xh4, 2 * pg.KR * pg.NR, wave, lane);
+      dma_to_lds<kNW, 0>(pa.tables + q.g_off, fld, 2 * pg.Kc * pg.M1, wave, lane);
+      coef_items<kNT, false>(ptid, 0, pg.nrow * pg.ncol, true, pa, q, pg, seed, pa.step0 + s, lds, pa.lds_x_half, no_noise);
+    }
+    STAMP(10);
+    // ---- P0: chain state of the window -> registers, in flight during the two MFMA stages ------------------------------
     double vb[KT], ve[KT];
-    auto state_loads = [&] {
+    {
+      relaunder();
       const cargs_t K = kargs();
       const Win G = win_of(K, rec_at(K, s));
+      // stores of an earlier accepted step must have landed before this step reads an overlapping halo window
+      if ((G.hr0 < pr1) && (pr0 < G.hr1) && (G.hc0 < pc1) && (pc0 < G.hc1)) __syncthreads();
       const rsrc_t r_bed = rsrc_bed(K);
       const rsrc_t r_en = rsrc_en(K);
       const int W = K->T.S.W;
@@ -209,35 +199,21 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
         vb[k] = StateIO<TS>::load(r_bed, valid ? g * (uint32_t)sizeof(TS) : kOOB);
         ve[k] = StateIO<TS>::load(r_en, inwin ? g * (uint32_t)sizeof(TS) : kOOB);
       }
-    };
-    {
-      const cargs_t K = kargs();
-      const Win G = win_of(K, rec_at(K, s));
-      // stores of an earlier accepted step must have landed before this step reads an overlapping halo window
-      if ((G.hr0 < pr1) && (pr0 < G.hr1) && (G.hc0 < pc1) && (pc0 < G.hc1)) __syncthreads();
     }
     STAMP(0);
-    const bool more = s + 1 < n_steps;
-    double dc0;
-    // The two roles are two separate code paths from here to stage 2 (same barriers, in the same order, on both): what one
-    // role keeps in registers -- the chain state and the stage-1 accumulators on one side, the Box-Muller temporaries on the
-    // other -- is then not live on the other path.
-    if (wave >= kNWC) {
-      // ---- matrix-core waves ----
-      const int mw = wave - kNWC;
-      state_loads();
-      // Everything older than the 2 KT state loads -- the LDS-DMA of this step's coefficient planes and DFT tables (issued
-      // after phase D of the previous step, or by the prologue), the previous step's stores -- must have landed; vmcnt
-      // counts in order.  Then a bare barrier: __syncthreads() would wait vmcnt(0), i.e. for the HBM loads just issued.
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(2 * KT) : "memory");
-      STAMP(2);
-      dc0 = lds[0];    // mean of the field = DC coefficient / n (proposal_device.h); read before T^T overlays the plane
+    // The table LDS-DMAs are older than the 2 KT state loads just issued: wait for everything but those (vmcnt counts in
+    // order) and for this wave's LDS writes; then a bare barrier.  __syncthreads() would wait vmcnt(0), i.e. for HBM.
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(2 * KT) : "memory");
+    STAMP(2);
+    // mean of the field = DC coefficient / n (proposal_device.h); read before T^T overlays the plane
+    const double dc0 = lds[0];
+    {
       v4f64 uc[kUPW], us[kUPW];
       {
         const cargs_t K = kargs();
         const ProposeArgs pa = load_c(&K->P);
         const PropScalars q = prop_rec(rec_at(K, s));
-        dft_stage1<kNWM, kUPW, true>(mw, ptid & 63, pa, q, prop_geom(pa, q.bh, q.bw), lds, lds + lds_xh4, uc, us);
+        dft_stage1<kNW, kUPW, true>(wave, ptid & 63, pa, q, prop_geom(pa, q.bh, q.bw), lds, lds + lds_xh4, uc, us);
       }
       STAMP(1);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has finished reading the planes
@@ -247,43 +223,11 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
         const ProposeArgs pa = load_c(&K->P);
         crec_t r = rec_at(K, s);
         relaunder();
-        dft_tt_write<kNWM, kUPW>(mw, ptid & 63, prop_geom(pa, r->bh, r->bw), lds, uc, us);
+        dft_tt_write<kNW, kUPW>(wave, ptid & 63, prop_geom(pa, r->bh, r->bw), lds, uc, us);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      STAMP(10);
-    } else {
-      // ---- coefficient waves: step s + 1 (about two thirds of its items beside stage 1, the rest beside stage 2) ----
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      STAMP(2);
-      dc0 = lds[0];
-      auto items = [&](const int part) {
-        relaunder();
-        const cargs_t K = kargs();
-        const ProposeArgs pa = load_c(&K->P);
-        const PropScalars q = prop_rec(rec_at(K, s + 1));
-        const PropGeom gn = prop_geom(pa, q.bh, q.bw);
-        const int n_item = gn.nrow * gn.ncol;
-        const int passes = (n_item + kNTV - 1) / kNTV;
-        const int n_split = min(n_item, ((2 * passes + 2) / 3) * kNTV);
-        coef_items<kNTV, false>(ptid, part ? n_split : 0, part ? n_item : n_split, part == 0, pa, q, gn, seed,
-                                pa.step0 + s + 1, K->coef + (size_t)chain * 4 * pa.lds_x_half, pa.lds_x_half, no_noise);
-      };
-      __builtin_amdgcn_s_setprio(2);
-      if (more) items(0);
-      __builtin_amdgcn_s_setprio(0);
-      STAMP(1);
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      STAMP(13);
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      STAMP(10);
-      __builtin_amdgcn_s_setprio(2);
-      if (more) items(1);
-      __builtin_amdgcn_s_setprio(0);
-      relaunder();
-      state_loads();       // lands under stage 2 / the standardisation
     }
-    // ---- S2: stage 2, output tile t on wave t of all 16 (at most 16 tiles; 12 or fewer for most block shapes, so the
-    // coefficient waves seldom own one) -----------------------------------------------------------------------------------
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // ---- S2: stage 2 (output tile t on wave t), standardise, scale x edge mask -> field tile --------------------------
     {
       const cargs_t K = kargs();
       const ProposeArgs pa = load_c(&K->P);
@@ -473,19 +417,8 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       }
     }
     STAMP(7);
-    __syncthreads();      // also: every wave is past phase D (flux tiles dead) and the coefficient waves' stores have landed
+    __syncthreads();
     STAMP(8);
-    if (more) {
-      // next step's coefficient planes (scratch -> LDS, past L1: they were written by other waves of this CU) and DFT
-      // tables, by LDS-DMA; they fly under the accept test and the commit and are awaited at the next step's first barrier
-      const cargs_t K = kargs();
-      const ProposeArgs pa = load_c(&K->P);
-      crec_t rn = rec_at(K, s + 1);
-      const PropGeom gn = prop_geom(pa, rn->bh, rn->bw);
-      dma_to_lds<kNW, 2>(K->coef + (size_t)chain * lds_xh4, lds, lds_xh4, wave, lane);
-      dma_to_lds<kNW, 0>(pa.tables + rn->fy_off, lds + lds_xh4, 2 * gn.KR * gn.NR, wave, lane);
-      dma_to_lds<kNW, 0>(pa.tables + rn->g_off, fld, 2 * gn.Kc * gn.M1, wave, lane);
-    }
     const int rl = (lane & 15) * 4;
     const double so = row16_sum(red[rl]);
     const double sn = row16_sum(red[rl + 1]);
@@ -570,7 +503,7 @@ static hipError_t launch_fused_t(const FusedArgs& a, hipStream_t st) {
 
 bool fused_supported(const FusedArgs& a) {
   return step_flux_supported(a.T) && a.P.tab_max > 0 && fused_lds_doubles(a) * sizeof(double) <= 160 * 1024 &&
-         2 * a.P.tiles1_max <= kNWM * kUPW && a.P.tiles2_max <= 16;
+         2 * a.P.tiles1_max <= kNW * kUPW && a.P.tiles2_max <= 16;
 }
 
 // One launch: propose_scalars_kernel for all steps must have filled a.P.scalars (n_chains x a.P.n_steps records).

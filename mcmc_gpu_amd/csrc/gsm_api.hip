@@ -26,8 +26,6 @@ struct gsm_context {
   int32_t *d_fy_off = nullptr, *d_g_off = nullptr;
   int lds_sx = 0, lds_st = 0, lds_x_half = 0, lds_tt = 0, prop_tiles = 0, prop_tiles1 = 0;
   int tables_len = 0, tab_max = 0;
-  double* d_coef = nullptr;      // fused chain kernel: coefficient planes of the next step, [n_chains][4 * lds_x_half]
-  size_t coef_cap = 0;
   PropScalars* d_scalars[2] = {nullptr, nullptr};
   size_t scalars_cap[2] = {0, 0};
   // Cholesky generator
@@ -125,7 +123,6 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_fy_off) hipFree(h->d_fy_off);
   if (h->d_g_off) hipFree(h->d_g_off);
   for (auto& p : h->d_scalars) if (p) hipFree(p);
-  if (h->d_coef) hipFree(h->d_coef);
   if (h->d_factors) hipFree(h->d_factors);
   for (auto& c : h->chol) { if (c.ints) hipFree(c.ints); if (c.zoff) hipFree(c.zoff); if (c.per_rec) hipFree(c.per_rec);
                             if (c.scale) hipFree(c.scale); if (c.zbuf) hipFree(c.zbuf); }
@@ -561,13 +558,6 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
         HIPCHK(h, hipMalloc(&sc.u, recs1 * sizeof(double)));
         sc.recs = recs1;
       }
-      const size_t coef_need = (size_t)h->n_chains * 4 * (size_t)h->lds_x_half;
-      if (h->coef_cap < coef_need) {
-        if (h->d_coef) { hipFree(h->d_coef); h->d_coef = nullptr; h->coef_cap = 0; }
-        HIPCHK(h, hipMalloc(&h->d_coef, coef_need * sizeof(double)));
-        h->coef_cap = coef_need;
-      }
-      fa.coef = h->d_coef;
       const int n_seg = (n_steps + seg_max - 1) / seg_max;
       std::vector<hipEvent_t> tev;
       if (h->timing) { tev.resize((size_t)2 * n_seg); for (auto& e : tev) HIPCHK(h, hipEventCreate(&e)); }

@@ -112,8 +112,6 @@ struct FusedArgs {
   StepArgs T;
   ProposeArgs P;
   int work_len, fld_len;   // LDS region sizes in doubles, set by launch_chain_fused
-  double* coef;            // [n_chains][4 * lds_x_half]: coefficient planes of the NEXT step, written by the four coefficient
-                           // waves while the other twelve run the matrix-core stages of the current one (L2-resident)
 };
 
 // scratch + factor table of the Cholesky proposal generator (cholesky_kernel.hip)

@@ -25,13 +25,14 @@ out = np.zeros((a.chains, 16), dtype=np.uint64)
 eng.lib.gsm_debug_stamps_fused.argtypes = [C.c_void_p, C.c_int32]
 rc = eng.lib.gsm_debug_stamps_fused(out.ctypes.data, a.chains)
 assert rc == 0, rc
-names = {15: "loop top", 0: "window + fence", 2: "P0 state loads + barrier A (DMA wait)", 1: "S1: stage 1 MFMA (wave 0)",
-         13: "S1 barrier (waits for coefficient waves)", 10: "T^T write + barrier", 11: "S2: stage 2 MFMA + mask loads",
-         14: "standardise (reduction + barrier)", 12: "emit -> LDS", 3: "emit barrier", 4: "A statics+flux", 5: "A barrier",
-         6: "D stencil", 7: "R wave-reduce", 8: "R barrier", 9: "DMA issue + decide + E commit"}
-order = [15, 0, 2, 1, 13, 10, 11, 14, 12, 3, 4, 5, 6, 7, 8, 9]
+names = {15: "loop top", 10: "P coefficients (Philox, Box-Muller, amplitude) + table DMA issue", 0: "window, fence, P0 issue state loads",
+         2: "barrier (slowest wave's coefficients, table DMA)", 1: "stage 1 MFMA", 13: "stage-1 barrier",
+         11: "T^T write + barrier + stage 2 MFMA + mask loads", 14: "standardise (reduction + barrier)", 12: "emit -> LDS",
+         3: "emit barrier", 4: "A statics+flux", 5: "A barrier", 6: "D stencil", 7: "R wave-reduce", 8: "R barrier",
+         9: "decide + E commit"}
+order = [15, 10, 0, 2, 1, 13, 11, 14, 12, 3, 4, 5, 6, 7, 8, 9]
 per = out.astype(np.float64).mean(axis=0) / a.steps
 print(f"fused launch {tm['step_ms']:.3f} ms for {a.steps} steps x {a.chains} chains; accept {np.mean(acc):.3f}")
 for k in order:
-    print(f"  {names[k]:34s} {per[k]:9.0f} cycles/step  ({100 * per[k] / per.sum():5.1f} %)")
+    print(f"  {names[k]:72s} {per[k]:9.0f} cycles/step  ({100 * per[k] / per.sum():5.1f} %)")
 print(f"  total                              {per.sum():9.0f} cycles/step")
