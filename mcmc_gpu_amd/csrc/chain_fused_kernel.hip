@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
   auto prop_rec = [&](crec_t r) {
     PropScalars q;
     q.scale = r->scale; q.nug = r->nug; q.aa = r->aa; q.m_const = r->m_const; q.m_kappa = r->m_kappa;
-    q.bh = r->bh; q.bw = r->bw; q.fy_off = r->fy_off; q.g_off = r->g_off; q.mask_off = r->mask_off;
+    q.bh = r->bh; q.bw = r->bw; q.fy_off = r->fy_off; q.g_off = r->g_off; q.pad = r->pad; q.mask_off = r->mask_off;
     return q;
   };
   for (int s = 0; s < n_steps; ++s) {

@@ -26,6 +26,9 @@ struct gsm_context {
   int32_t *d_fy_off = nullptr, *d_g_off = nullptr;
   int lds_sx = 0, lds_st = 0, lds_x_half = 0, lds_tt = 0, prop_tiles = 0, prop_tiles1 = 0;
   int tables_len = 0, tab_max = 0;
+  double* d_k2 = nullptr;        // per-size k^2 tables of the spectral amplitude (depend on rf.resolution)
+  int32_t* d_k2_off = nullptr;
+  double k2_resolution = 0.0;
   PropScalars* d_scalars[2] = {nullptr, nullptr};
   size_t scalars_cap[2] = {0, 0};
   // Cholesky generator
@@ -123,6 +126,8 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_fy_off) hipFree(h->d_fy_off);
   if (h->d_g_off) hipFree(h->d_g_off);
   for (auto& p : h->d_scalars) if (p) hipFree(p);
+  if (h->d_k2) hipFree(h->d_k2);
+  if (h->d_k2_off) hipFree(h->d_k2_off);
   if (h->d_factors) hipFree(h->d_factors);
   for (auto& c : h->chol) { if (c.ints) hipFree(c.ints); if (c.zoff) hipFree(c.zoff); if (c.per_rec) hipFree(c.per_rec);
                             if (c.scale) hipFree(c.scale); if (c.zbuf) hipFree(c.zbuf); }
@@ -289,6 +294,15 @@ extern "C" int gsm_set_blocks(gsm_handle h, int32_t n_sizes, const int32_t* bh, 
     h->tab_max = std::max(h->tab_max, 2 * ((nrow + 3) & ~3) * ((nrow + 15) & ~15));
     h->tab_max = std::max(h->tab_max, 2 * ((ncol + 3) & ~3) * ((ncol + 15) & ~15));
   }
+  {
+    std::vector<int32_t> k2_off((size_t)n_sizes);
+    int32_t tot = 0;
+    for (int i = 0; i < n_sizes; ++i) { k2_off[i] = tot; tot += (bh[i] / 2 + 1) * (bw[i] / 2 + 1); }
+    HIPCHK(h, dup_device(&h->d_k2_off, k2_off.data(), k2_off.size(), st));
+    if (h->d_k2) { hipFree(h->d_k2); h->d_k2 = nullptr; }
+    HIPCHK(h, hipMalloc(&h->d_k2, sizeof(double) * (size_t)tot));
+    h->k2_resolution = 0.0;
+  }
   HIPCHK(h, dup_device(&h->d_tables, tb.data(), tb.size(), st));
   HIPCHK(h, dup_device(&h->d_fy_off, fy_off.data(), fy_off.size(), st));
   HIPCHK(h, dup_device(&h->d_g_off, g_off.data(), g_off.size(), st));
@@ -391,6 +405,14 @@ static int check_propose_ready(gsm_handle h, const gsm_rf_params* rf, const char
   return GSM_OK;
 }
 
+// k^2 tables of the spectral amplitude for this resolution (built on first use, rebuilt when the resolution changes)
+static int ensure_k2(gsm_handle h, const gsm_rf_params* rf, hipStream_t st) {
+  if (rf->generator != GSM_GEN_SPECTRAL || h->k2_resolution == rf->resolution) return GSM_OK;
+  HIPCHK(h, launch_k2_tables(h->B, h->d_k2_off, rf->resolution, h->d_k2, st));
+  h->k2_resolution = rf->resolution;
+  return GSM_OK;
+}
+
 static int ensure_scalars(gsm_handle h, int slot, size_t recs) {
   if (h->scalars_cap[slot] >= recs) return GSM_OK;
   if (h->d_scalars[slot]) { hipFree(h->d_scalars[slot]); h->d_scalars[slot] = nullptr; h->scalars_cap[slot] = 0; }
@@ -426,6 +448,7 @@ static ProposeArgs make_propose(gsm_handle h, const gsm_rf_params* rf, int n_ste
   p.centres = h->d_centres; p.n_centres = h->n_centres;
   p.tables = h->d_tables; p.tables_len = h->tables_len; p.tab_max = h->tab_max; p.fy_off = h->d_fy_off; p.g_off = h->d_g_off;
   p.lds_sx = h->lds_sx; p.lds_st = h->lds_st; p.lds_x_half = h->lds_x_half; p.lds_tt = h->lds_tt;
+  p.k2tab = h->d_k2; p.k2_off = h->d_k2_off;
   p.lds_main = std::max(4 * h->lds_x_half, h->lds_tt);
   p.tiles1_max = h->prop_tiles1; p.tiles2_max = h->prop_tiles;
   return p;
@@ -442,6 +465,7 @@ extern "C" int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, 
   if (field_stride < (int64_t)h->B.max_bh * h->B.max_bw) return fail(h, GSM_E_ARG, "gsm_propose_philox: field_stride too small");
   HIPCHK(h, hipSetDevice(h->device));
   { int rc2 = ensure_scalars(h, 0, (size_t)h->n_chains * n_steps); if (rc2) return rc2; }
+  { int rc2 = ensure_k2(h, rf, (hipStream_t)stream); if (rc2) return rc2; }
   ProposeArgs p = make_propose(h, rf, n_steps, step0, seeds);
   p.size_idx = size_idx; p.centre = centre; p.u = u; p.fields = fields; p.field_stride = field_stride;
   p.rf_scalars = rf_scalars; p.scalars = h->d_scalars[0];
@@ -480,6 +504,7 @@ extern "C" int gsm_spectral_from_noise(gsm_handle h, int32_t n_fields, const int
   for (int32_t v : si)
     if (v < 0 || v >= h->B.n_sizes) return fail(h, GSM_E_DEVICE_DATA, "gsm_spectral_from_noise: size index out of range");
   { int rc2 = ensure_scalars(h, 0, (size_t)n_fields); if (rc2) return rc2; }
+  { int rc2 = ensure_k2(h, &rfs, st); if (rc2) return rc2; }
   ProposeArgs p = make_propose(h, &rfs, n_fields, 0, nullptr);
   p.n_chains = 1;
   p.fields = fields; p.field_stride = field_stride; p.scalars = h->d_scalars[0];
@@ -524,6 +549,7 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(h, hipSetDevice(h->device));
   if (batch > n_steps) batch = n_steps;
+  { int rc2 = ensure_k2(h, rf, st); if (rc2) return rc2; }
   // Spectral generator: one fused launch (chain_fused_kernel.hip) -- proposals are generated and consumed on the CU,
   // no field scratch, no second stream.  GSM_FUSED=0 keeps the two-kernel pipeline (also used by the Cholesky generator
   // and by block tables beyond the fused kernel's LDS budget).

@@ -71,9 +71,10 @@ struct StepArgs {
 // per-proposal scalars written by propose_scalars_kernel and read (uniformly) by propose_kernel
 struct PropScalars {
   double scale, nug, range_x, range_y, u;
-  double aa, m_const, m_kappa;   // spectral-amplitude parameters (MCMC.py:209-239)
+  double aa, m_const, m_kappa;   // spectral-amplitude parameters (MCMC.py:209-239); m_const = log(Matern constant) / 2
   int32_t si, row, col, bh;
-  int32_t bw, fy_off, g_off, pad;   // block shape and DFT-table offsets: no dependent table look-ups in propose_kernel
+  int32_t bw, fy_off, g_off, pad;   // block shape and DFT-table offsets: no dependent table look-ups in propose_kernel;
+                                    // pad = offset of this shape's k^2 table in ProposeArgs::k2tab
   int64_t mask_off;
 };
 
@@ -103,6 +104,8 @@ struct ProposeArgs {
   int lds_tt;              // doubles of T^T
   int lds_main;            // max(4 * lds_x_half, lds_tt): T^T overlays X
   int tiles1_max, tiles2_max;  // largest stage-1 / stage-2 output-tile counts over the block table
+  const double* k2tab;     // (sqrt(kx^2 + ky^2) + 1e-10)^2 on ky <= bh/2, kx <= bw/2, one [nrow][ncol] table per block size
+  const int32_t* k2_off;   // [n_sizes] offsets into k2tab
   PropScalars* scalars;    // device scratch, n_chains * n_steps records
   int dbg;                 // diagnostics only (GSM_PROPOSE_DBG): bit0 cheap coefficients, bit1 skip stage 1, bit2 skip stage 2
 };
@@ -169,6 +172,7 @@ hipError_t launch_pack_static(const StaticFields& S, double2* svx, double2* svy,
 hipError_t launch_residual(const StaticFields& S, int n_chains, const double* beds, double* out, hipStream_t st);
 hipError_t launch_propose(const ProposeArgs& a, hipStream_t st);
 hipError_t launch_propose_scalars(const ProposeArgs& a, hipStream_t st);
+hipError_t launch_k2_tables(const BlockTable& B, const int32_t* k2_off, double resolution, double* k2tab, hipStream_t st);
 hipError_t launch_spectral_from_noise(const ProposeArgs& a, const int32_t* size_idx, const double* rf_scalars, const double* noise_re,
                                       const double* noise_im, const double* nugget_field, hipStream_t st);
 hipError_t launch_chain_fused(const FusedArgs& a, hipStream_t st);

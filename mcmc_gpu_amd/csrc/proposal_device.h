@@ -16,6 +16,21 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t pmagic(uint32_t d) { return (uint32_t)(0xFFFFFFFFu / d) + 1u; }
 
+// a * b + C and a * C with the constant C read from a scalar register pair.  Written as inline assembly because the
+// compiler otherwise copies every fp64 literal into a VGPR pair first (two v_mov_b32 per constant, re-done at every use
+// since machine LICM is off for this file): with ~35 polynomial constants per work item that was a tenth of the
+// coefficient phase's vector instructions.  s_mov_b32 on the scalar unit issues beside another wave's vector instruction.
+__device__ __forceinline__ double fma_sc(double a, double b, double C) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(C));
+  return r;
+}
+__device__ __forceinline__ double mul_sc(double a, double C) {
+  double r;
+  asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(C));
+  return r;
+}
+
 // log(x) for positive, finite, normal x (here: uniforms in [2^-53, 1] and spectral-density arguments): the fdlibm
 // e_log.c algorithm (argument reduction to [sqrt(1/2), sqrt(2)), s = f / (2 + f), degree-7 minimax in s^2; error
 // < 1 ulp) without the special-case handling and the double-double arithmetic of the library routine -- about half its
@@ -37,14 +52,35 @@ __device__ __forceinline__ double log_pos(double x) {
   double s = f * y;
   s = __fma_rn(__fma_rn(-s, d, f), y, s);
   const double z = s * s, w = z * z;
-  const double t1 = w * __fma_rn(w, __fma_rn(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
-                                 3.999999999940941908e-01);
-  const double t2 = z * __fma_rn(w, __fma_rn(w, __fma_rn(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
-                                             2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double t1 = w * fma_sc(w, fma_sc(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
+                               3.999999999940941908e-01);
+  const double t2 = z * fma_sc(w, fma_sc(w, fma_sc(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                         2.857142874366239149e-01), 6.666666666666735130e-01);
   const double R = t2 + t1;
   const double hfsq = 0.5 * f * f;
   const double dk = (double)k;
-  return dk * 6.93147180369123816490e-01 - ((hfsq - __fma_rn(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+  return mul_sc(dk, 6.93147180369123816490e-01) - ((hfsq - __fma_rn(s, hfsq + R, mul_sc(dk, 1.90821492927058770002e-10))) - f);
+}
+
+// exp(x) for finite x, |x| < 700 (spectral amplitudes): k = rint(x / ln 2), r = x - k ln2_hi - k ln2_lo (|r| <= 0.3466),
+// degree-12 Taylor polynomial of exp(r) (truncation 1.7e-16 relative), scaled by 2^k with v_ldexp_f64 (which also takes
+// care of underflow towards 0).  About half the instructions of the library routine; error < 1.5 ulp.
+__device__ __forceinline__ double exp_lean(double x) {
+  const double kf = __builtin_rint(mul_sc(x, 1.44269504088896338700e+00));
+  const double r = fma_sc(kf, -1.90821492927058770002e-10, fma_sc(kf, -6.93147180369123816490e-01, x));
+  double p = fma_sc(r, 2.08767569878680989792e-09, 2.50521083854417187751e-08);      // 1/12!, 1/11!
+  p = fma_sc(r, p, 2.75573192239858906526e-07);     // 1/10!
+  p = fma_sc(r, p, 2.75573192239858906526e-06);     // 1/9!
+  p = fma_sc(r, p, 2.48015873015873015873e-05);     // 1/8!
+  p = fma_sc(r, p, 1.98412698412698412698e-04);     // 1/7!
+  p = fma_sc(r, p, 1.38888888888888888889e-03);     // 1/6!
+  p = fma_sc(r, p, 8.33333333333333333333e-03);     // 1/5!
+  p = fma_sc(r, p, 4.16666666666666666667e-02);     // 1/4!
+  p = fma_sc(r, p, 1.66666666666666666667e-01);     // 1/3!
+  p = fma_sc(r, p, 0.5);
+  p = __fma_rn(r, p, 1.0);
+  p = __fma_rn(r, p, 1.0);
+  return ldexp(p, (int)kf);
 }
 
 // (sin, cos)(2 pi u) for u in [0, 1): quadrant reduction on a = 4u (exact: n = rint(a), f = a - n in [-1/2, 1/2]), then the
@@ -53,15 +89,15 @@ __device__ __forceinline__ double log_pos(double x) {
 __device__ __forceinline__ void sincos_2pi(double u, double& s, double& c) {
   const double a = 4.0 * u;
   const double n = __builtin_rint(a);
-  const double x = (a - n) * 1.57079632679489661923;
+  const double x = mul_sc(a - n, 1.57079632679489661923);
   const double z = x * x;
-  const double ps = __fma_rn(z, __fma_rn(z, __fma_rn(z, __fma_rn(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
-                                                      2.75573137070700676789e-06), -1.98412698298579493134e-04),
-                             8.33333333332248946124e-03);
-  const double sn = __fma_rn(x * z, __fma_rn(z, ps, -1.66666666666666324348e-01), x);
-  const double pc = __fma_rn(z, __fma_rn(z, __fma_rn(z, __fma_rn(z, __fma_rn(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
-                                                                  -2.75573143513906633035e-07), 2.48015872894767294178e-05),
-                                          -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double ps = fma_sc(z, fma_sc(z, fma_sc(z, fma_sc(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                                2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                           8.33333333332248946124e-03);
+  const double sn = __fma_rn(x * z, fma_sc(z, ps, -1.66666666666666324348e-01), x);
+  const double pc = fma_sc(z, fma_sc(z, fma_sc(z, fma_sc(z, fma_sc(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                          -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                    -1.38888888888741095749e-03), 4.16666666666666019037e-02);
   const double hz = 0.5 * z, w = 1.0 - hz;
   const double cs = w + (((1.0 - w) - hz) + z * (z * pc));
   const int q = (int)n;                    // 0..4
@@ -94,19 +130,17 @@ __device__ __forceinline__ double wavenumber(int k, int n, double inv) {
   return ((double)kk * inv) * 2.0 * M_PI;
 }
 
-// sqrt(S(k)) of MCMC.py:227-239, :244
-__device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const PropScalars& sc, int ky, int kx, int bh, int bw,
-                                              double inv_x, double inv_y) {
-  const double kxv = wavenumber(kx, bw, inv_x), kyv = wavenumber(ky, bh, inv_y);
-  const double k = sqrt(kxv * kxv + kyv * kyv) + 1e-10;
-  double Sp;
-  if (P.model == GSM_MODEL_GAUSSIAN) { const double ak = sc.aa * k; Sp = exp(-0.5 * (ak * ak)); }
-  else if (P.model == GSM_MODEL_EXPONENTIAL) { const double ak = sc.aa * k; Sp = exp(-1.5 * log_pos(1.0 + ak * ak)); }
-  else {
-    const double nu = (P.smoothness != 0.0) ? P.smoothness : 1.0;
-    Sp = sc.m_const * exp((-nu - 1.0) * log_pos(sc.m_kappa + 4.0 * M_PI * (k * k)));
-  }
-  return sqrt(Sp);
+// sqrt(S(k)) of MCMC.py:227-239, :244.  k2 = (sqrt(kx^2 + ky^2) + 1e-10)^2 comes from a per-shape table (it depends on
+// nothing that is drawn, gsm_api.hip: k2_table_kernel); the outer square root is taken in the exponent:
+//   Gaussian     sqrt(exp(-(a k)^2 / 2))            = exp(-(a k)^2 / 4)
+//   Exponential  sqrt((1 + (a k)^2)^-1.5)           = exp(-0.75 log(1 + (a k)^2))
+//   Matern       sqrt(C (kappa + 4 pi k^2)^(-nu-1)) = exp(log(C) / 2 - (nu + 1) / 2 * log(kappa + 4 pi k^2))
+// sc.m_const holds log(C) / 2 (propose_scalars_kernel).  Same values as the reference's formula to a few ulp.
+__device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const PropScalars& sc, const double k2) {
+  if (P.model == GSM_MODEL_GAUSSIAN) return exp_lean(-0.25 * ((sc.aa * sc.aa) * k2));
+  if (P.model == GSM_MODEL_EXPONENTIAL) return exp_lean(-0.75 * log_pos(1.0 + (sc.aa * sc.aa) * k2));
+  const double nu = (P.smoothness != 0.0) ? P.smoothness : 1.0;
+  return exp_lean(__fma_rn(-0.5 * (nu + 1.0), log_pos(sc.m_kappa + 4.0 * M_PI * k2), sc.m_const));
 }
 
 // DFT folding used below (n even, h = n/2).  With P[k] = X[k] + X[n-k], M[k] = X[k] - X[n-k] (0 < k < h; P = X, M = 0
@@ -180,9 +214,10 @@ __device__ __forceinline__ void coef_items(const int t, const int i_lo, const in
       }
     }
   }
-  const double inv_x = 1.0 / ((double)bw * P.resolution), inv_y = 1.0 / ((double)bh * P.resolution);
   const uint32_t m_nc = pmagic((uint32_t)ncol);
+  const double* __restrict__ k2tab = a.k2tab + sc.pad;          // this shape's [nrow][ncol] table (pad = its offset)
   for (int i = i_lo + t; i < i_hi && !(a.dbg & 32); i += NTH) {
+    const double k2 = k2tab[i];                                 // requested first: lands under the Box-Muller code
     const int ky = (int)__umulhi((uint32_t)i, m_nc);
     const int kx = i - ky * ncol;
     const int kyc = bh - ky;
@@ -190,7 +225,7 @@ __device__ __forceinline__ void coef_items(const int t, const int i_lo, const in
     double amp, g1 = 0.0, g2 = 0.0, h1 = 0.0, h2 = 0.0;
     double ar, ai, br = 0.0, bi = 0.0;   // X[ky], X[bh - ky]
     if (NOISE_IN) {
-      amp = spectral_amp(P, sc, ky, kx, bh, bw, inv_x, inv_y);
+      amp = spectral_amp(P, sc, k2);
       const int nky = (ky == 0) ? 0 : kyc, nkx = (kx == 0) ? 0 : bw - kx;      // -k modulo the block shape
       ar = amp * (0.5 * (noise.re[ky * bw + kx] + noise.re[nky * bw + nkx]));
       ai = amp * (0.5 * (noise.im[ky * bw + kx] - noise.im[nky * bw + nkx]));
@@ -201,12 +236,12 @@ __device__ __forceinline__ void coef_items(const int t, const int i_lo, const in
     } else {
       if (a.dbg & 1) { amp = 1.0; g1 = ky; g2 = kx; h1 = 1.0; h2 = 2.0; }
       else {
-        amp = spectral_amp(P, sc, ky, kx, bh, bw, inv_x, inv_y);
         normals2(seed, step, kStreamSpectrum, (uint32_t)(ky * ncol + kx), g1, g2);
         // drawn unconditionally (counter-based: an unused draw costs nothing downstream): one straight-line block for
-        // both Box-Muller evaluations, so their polynomial constants are materialised once and the two chains interleave
+        // both Box-Muller evaluations, so the two chains interleave
         normals2(seed, step, kStreamSpectrum, (uint32_t)(kyc * ncol + kx), h1, h2);
         if (!paired) { h1 = 0.0; h2 = 0.0; }
+        amp = spectral_amp(P, sc, k2);
       }
       if (kx > 0 && kx < hw) {
         ar = amp * (g1 * M_SQRT1_2); ai = amp * (g2 * M_SQRT1_2);

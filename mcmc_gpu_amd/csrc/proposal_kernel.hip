@@ -43,14 +43,14 @@ __device__ __forceinline__ void spectral_params(PropScalars& r, const gsm_rf_par
   r.m_const = 0.0; r.m_kappa = 0.0;
   if (P.model == GSM_MODEL_MATERN) {
     const double nu = (P.smoothness != 0.0) ? P.smoothness : 1.0;
-    r.m_const = (4.0 * M_PI * tgamma(nu + 1.0) * pow(2.0 * nu, nu)) / (tgamma(nu) * pow(r.aa, 2.0 * nu));
+    r.m_const = 0.5 * log((4.0 * M_PI * tgamma(nu + 1.0) * pow(2.0 * nu, nu)) / (tgamma(nu) * pow(r.aa, 2.0 * nu)));
     r.m_kappa = 2.0 * nu / (r.aa * r.aa);
   }
 }
 
 // block shape, DFT-table offsets and mask offset of size index r.si
 __device__ __forceinline__ void block_shape(PropScalars& r, const ProposeArgs& a) {
-  r.pad = 0;
+  r.pad = a.k2_off[r.si];
   r.bh = a.B.bh[r.si];
   r.bw = a.B.bw[r.si];
   r.fy_off = a.fy_off[r.bh];
@@ -111,6 +111,29 @@ __global__ __launch_bounds__(NT, NT / 256) void propose_kernel(const ProposeArgs
   double* __restrict__ out = a.fields + rec * a.field_stride;
   propose_field<NT>((int)threadIdx.x, a, sc, a.seeds[chain], a.step0 + s, plds, red, out,
                     [bw = sc.bw](int y, int x) { return y * bw + x; });
+}
+
+// k^2 tables: for block size s the [bh/2 + 1][bw/2 + 1] values (sqrt(kx^2 + ky^2) + 1e-10)^2 with kx, ky = 2 pi fftfreq
+// (MCMC.py:221-224) -- one workgroup per block size.  They depend on the grid resolution only, which arrives with the
+// random-field parameters: rebuilt when it changes.
+__global__ __launch_bounds__(256) void k2_table_kernel(const BlockTable B, const int32_t* __restrict__ k2_off, double resolution,
+                                                       double* __restrict__ k2tab) {
+  const int si = blockIdx.x;
+  const int bh = B.bh[si], bw = B.bw[si];
+  const int nrow = bh / 2 + 1, ncol = bw / 2 + 1;
+  const double inv_x = 1.0 / ((double)bw * resolution), inv_y = 1.0 / ((double)bh * resolution);
+  double* out = k2tab + k2_off[si];
+  for (int i = threadIdx.x; i < nrow * ncol; i += 256) {
+    const int ky = i / ncol, kx = i - ky * ncol;
+    const double kxv = wavenumber(kx, bw, inv_x), kyv = wavenumber(ky, bh, inv_y);
+    const double k = sqrt(kxv * kxv + kyv * kyv) + 1e-10;
+    out[i] = k * k;
+  }
+}
+
+hipError_t launch_k2_tables(const BlockTable& B, const int32_t* k2_off, double resolution, double* k2tab, hipStream_t st) {
+  hipLaunchKernelGGL(k2_table_kernel, dim3(B.n_sizes), dim3(256), 0, st, B, k2_off, resolution, k2tab);
+  return hipGetLastError();
 }
 
 // gsm_spectral_from_noise: scalar records from caller-supplied (size index, scale, nugget, ranges) ...
