@@ -10,7 +10,7 @@ vals = {n: [] for n in names}
 for r in range(reps):
     for n in names:
         env = dict(os.environ, GSM_LIB=str(ROOT / "mcmc_gpu_amd" / f"libgsm_{n}.so"))
-        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "8", "--warmup", "1", "--no-cpu-baseline"],
+        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "1", "--inner", "1024", "--no-cpu-baseline", "--no-extras"],
                              env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
         vals[n].append(json.loads(out)["value"])
 base = sorted(vals[names[0]])[reps // 2]

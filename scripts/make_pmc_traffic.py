@@ -23,8 +23,15 @@ fused = [k for k in F if 'chain_fused_kernel' in k][0]
 f_fetch = plane / (F[copy] * 1024)
 f_write = plane / (Wr[copy] * 1024)
 alg = sum(w['algorithmic_bytes_launch'] for w in work) / len(work)
+import subprocess
+try:
+    commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except Exception:
+    commit = None
+import os
 res = {
-    "grid": 256, "chains": 1024, "steps_per_launch": work[0]['steps'],
+    "grid": 256, "chains": 1024, "state": "f64", "steps_per_launch": work[0]['steps'],
+    "commit": os.environ.get("GSM_COMMIT") or commit,
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over scripts/pmc_fused.py; KiB units; "
               "read side multiplied by the factor measured on gsm::stream_copy_kernel (known 512 MiB)",
     "calibration": {"kernel": copy, "known_bytes": plane, "FETCH_SIZE_KiB": F[copy], "WRITE_SIZE_KiB": Wr[copy],
@@ -52,5 +59,10 @@ if sq_dirs:
         chain_steps = res["chains"] * res["steps_per_launch"]
         res["valu_wave_instructions_per_chain_step"] = sq.get("SQ_INSTS_VALU", 0.0) / chain_steps
         res["mfma_instructions_per_chain_step"] = sq.get("SQ_INSTS_MFMA", 0.0) / chain_steps
+        res["salu_instructions_per_chain_step"] = sq.get("SQ_INSTS_SALU", 0.0) / chain_steps
+        if "SQ_WAIT_ANY" in sq:
+            res["wait_any_frac_of_wave_cycles"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
+        if "SQ_LDS_BANK_CONFLICT" in sq and sq.get("SQ_LDS_IDX_ACTIVE"):
+            res["lds_bank_conflict_frac"] = sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"]
 json.dump(res, open(out, 'w'), indent=1)
 print(json.dumps(res, indent=1))
