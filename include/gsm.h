@@ -140,8 +140,9 @@ int gsm_run_replay(gsm_handle h, int32_t n_steps, void* beds, void* energy, uint
  * its edge mask), into the same layout gsm_run_replay consumes.  rf_scalars (optional, may be NULL)
  * [dev, n_chains*n_steps*4] receives (scale, nugget, range_x, range_y).
  * Key = seeds[c] [dev, n_chains]; counters are functions of (absolute step, draw index) only, so a run
- * split into segments reproduces the unsplit run.  The spectral kernel's LDS planes and accumulator tiling cover
- * blocks up to 80 x 80 (more when one side is shorter); larger tables return GSM_E_UNSUPPORTED.
+ * split into segments reproduces the unsplit run.  Block tables up to about 110 x 110 (the four coefficient planes must fit
+ * 160 KiB of LDS, at most 32 output tiles of 16 x 16 per DFT stage); larger tables return GSM_E_UNSUPPORTED.  Tables beyond
+ * ~80 x 80 use a wider instantiation of the proposal kernel and, in gsm_run_philox, the two-kernel pipeline.
  * Replaces: RandField.get_rfblock + spectral_synthesis_field (MCMC.py:742-778, :176-254), the centre
  * rejection loop (MCMC.py:1253-1261) and rng.random() (MCMC.py:1336). */
 int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, const uint64_t* seeds,

@@ -410,18 +410,23 @@ __device__ __forceinline__ void mask_prefetch(const int w, const int lane, const
 // and write nothing.  All 16 slots must be written: slot t by its owner, or by wave 0 of the owners if t >= n_tiles...
 template <int NW, int MAXT>
 __device__ __forceinline__ double tiles_sum(const double (&part)[MAXT], const int n_tiles, double* red, const int w, const int lane) {
-  static_assert(NW * MAXT >= 16, "the 16 tile slots must all have an owner");
+  // 16 tile slots (every block table the fused kernel takes; all forms then add them in the same order: bit-identical
+  // fields), or 32 for the wide instantiation of the stand-alone kernel (blocks beyond ~80 x 80)
+  constexpr int SLOTS = (NW * MAXT > 16) ? 32 : 16;
+  static_assert(NW * MAXT >= 16, "every tile slot must have an owner");
   if (w >= 0) {
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       const double ws = dev::wave64_sum(part[j]);
       const int t = w + j * NW;
-      if (lane == 0 && t < 16) red[t] = (t < n_tiles) ? ws : 0.0;   // all 16 slots are written
+      if (lane == 0 && t < SLOTS) red[t] = (t < n_tiles) ? ws : 0.0;   // all slots are written
     }
   }
   // only LDS traffic has to be complete here: a bare barrier leaves the caller's global loads in flight
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  return dev::row16_sum(red[lane & 15]);   // fixed tree over the 16 tile slots: the same value in every lane
+  double r = dev::row16_sum(red[lane & 15]);   // fixed tree over the tile slots: the same value in every lane
+  if (SLOTS == 32) r += dev::row16_sum(red[16 + (lane & 15)]);
+  return r;
 }
 
 // ---- standardise (MCMC.py:248) on the register-resident field -------------------------------------
@@ -529,11 +534,12 @@ __device__ __forceinline__ void nugget_pass(const int t, const ProposeArgs& a, c
 // ---- all stages in turn, by all NT threads of the workgroup (stand-alone kernels) ------------------------------------
 // plds: LDS work area of a.lds_main doubles; red: 32 doubles of LDS.  Contains workgroup barriers: every thread must call
 // it with the same (uniform) arguments.  On return other waves may still be reading `red`.
-template <int NT, bool NOISE_IN = false, class OMap>
+// WIDE = 2: twice the output tiles per wave (32 stage-2 tiles, 64 stage-1 units) for block tables beyond ~80 x 80.
+template <int NT, bool NOISE_IN = false, int WIDE = 1, class OMap>
 __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& a, const PropScalars& sc, const uint64_t seed,
                                               const int64_t step, double* plds, double* red, double* __restrict__ out, OMap omap,
                                               const NoiseIn noise = NoiseIn{nullptr, nullptr, nullptr}) {
-  constexpr int NW = NT / 64, MAXT = 16 / NW, UPW = 32 / NW;
+  constexpr int NW = NT / 64, MAXT = WIDE * 16 / NW, UPW = WIDE * 32 / NW;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const PropGeom g = prop_geom(a, sc.bh, sc.bw);

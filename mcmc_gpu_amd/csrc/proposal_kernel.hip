@@ -99,9 +99,10 @@ __global__ __launch_bounds__(256) void propose_scalars_kernel(const ProposeArgs 
   }
 }
 
-// One workgroup of NT threads per (chain, step); body in proposal_device.h.
-template <int NT>
-__global__ __launch_bounds__(NT, NT / 256) void propose_kernel(const ProposeArgs a) {
+// One workgroup of NT threads per (chain, step); body in proposal_device.h.  WIDE = 2: block tables whose largest shape
+// needs more than 16 stage-2 output tiles (beyond ~80 x 80): one workgroup per CU, twice the accumulators per wave.
+template <int NT, int WIDE>
+__global__ __launch_bounds__(NT, (WIDE == 1) ? NT / 256 : 1) void propose_kernel(const ProposeArgs a) {
   extern __shared__ double plds[];
   double* red = plds + a.lds_main;         // [32]
   const int s = blockIdx.x, chain = blockIdx.y;
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(NT, NT / 256) void propose_kernel(const ProposeArgs
   const PropScalars sc = a.scalars[rec];
   if (a.dbg & 64) { if (threadIdx.x == 0) a.fields[rec * a.field_stride] = (double)sc.bh; return; }
   double* __restrict__ out = a.fields + rec * a.field_stride;
-  propose_field<NT>((int)threadIdx.x, a, sc, a.seeds[chain], a.step0 + s, plds, red, out,
-                    [bw = sc.bw](int y, int x) { return y * bw + x; });
+  propose_field<NT, false, WIDE>((int)threadIdx.x, a, sc, a.seeds[chain], a.step0 + s, plds, red, out,
+                                 [bw = sc.bw](int y, int x) { return y * bw + x; });
 }
 
 // k^2 tables: for block size s the [bh/2 + 1][bw/2 + 1] values (sqrt(kx^2 + ky^2) + 1e-10)^2 with kx, ky = 2 pi fftfreq
@@ -153,18 +154,21 @@ __global__ __launch_bounds__(256) void noise_scalars_kernel(const ProposeArgs a,
 }
 
 // ... and the synthesis itself: propose_field with the coefficients formed from the caller's noise planes
-__global__ __launch_bounds__(512, 2) void spectral_from_noise_kernel(const ProposeArgs a, const double* __restrict__ noise_re,
-                                                                     const double* __restrict__ noise_im,
-                                                                     const double* __restrict__ nugget_field) {
+template <int WIDE>
+__global__ __launch_bounds__(512, (WIDE == 1) ? 2 : 1) void spectral_from_noise_kernel(const ProposeArgs a, const double* __restrict__ noise_re,
+                                                                                       const double* __restrict__ noise_im,
+                                                                                       const double* __restrict__ nugget_field) {
   extern __shared__ double plds[];
   double* red = plds + a.lds_main;
   const int64_t rec = blockIdx.x;
   const PropScalars sc = a.scalars[rec];
   const NoiseIn nz{noise_re + rec * a.field_stride, noise_im + rec * a.field_stride,
                    nugget_field ? nugget_field + rec * a.field_stride : nullptr};
-  propose_field<512, true>((int)threadIdx.x, a, sc, 0, 0, plds, red, a.fields + rec * a.field_stride,
-                           [bw = sc.bw](int y, int x) { return y * bw + x; }, nz);
+  propose_field<512, true, WIDE>((int)threadIdx.x, a, sc, 0, 0, plds, red, a.fields + rec * a.field_stride,
+                                 [bw = sc.bw](int y, int x) { return y * bw + x; }, nz);
 }
+
+static bool wide_table(const ProposeArgs& a) { return a.tiles2_max > 16 || a.tiles1_max > 16; }
 
 hipError_t launch_spectral_from_noise(const ProposeArgs& a, const int32_t* size_idx, const double* rf_scalars,
                                       const double* noise_re, const double* noise_im, const double* nugget_field, hipStream_t st) {
@@ -172,12 +176,14 @@ hipError_t launch_spectral_from_noise(const ProposeArgs& a, const int32_t* size_
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)spectral_from_noise_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)spectral_from_noise_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)spectral_from_noise_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   hipLaunchKernelGGL(noise_scalars_kernel, dim3((unsigned)((a.n_steps + 255) / 256)), dim3(256), 0, st, a, size_idx, rf_scalars);
-  hipLaunchKernelGGL(spectral_from_noise_kernel, dim3(a.n_steps), dim3(512), lds, st, a, noise_re, noise_im, nugget_field);
+  if (wide_table(a)) hipLaunchKernelGGL(spectral_from_noise_kernel<2>, dim3(a.n_steps), dim3(512), lds, st, a, noise_re, noise_im, nugget_field);
+  else hipLaunchKernelGGL(spectral_from_noise_kernel<1>, dim3(a.n_steps), dim3(512), lds, st, a, noise_re, noise_im, nugget_field);
   return hipGetLastError();
 }
 
@@ -185,20 +191,22 @@ hipError_t launch_propose(const ProposeArgs& a_in, hipStream_t st) {
   ProposeArgs a = a_in;
   { static int dbg = -1; if (dbg < 0) { const char* v = getenv("GSM_PROPOSE_DBG"); dbg = v ? atoi(v) : 0; } a.dbg = dbg; }
   const size_t lds = ((size_t)a.lds_main + 32) * sizeof(double);
-  static int nt = -1;   // GSM_PROPOSE_NT=1024: the fused kernel's geometry (tests: bit-identical fields)
+  static int nt = -1;   // GSM_PROPOSE_NT=1024: the fused kernel's workgroup size (tests: bit-identical fields)
   if (nt < 0) { const char* v = getenv("GSM_PROPOSE_NT"); nt = (v && atoi(v) == 1024) ? 1024 : 512; }
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)propose_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)propose_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)propose_kernel<512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)propose_kernel<1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)propose_kernel<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int64_t nrec = (int64_t)a.n_chains * a.n_steps;
   hipLaunchKernelGGL(propose_scalars_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, st, a);
-  if (nt == 1024) hipLaunchKernelGGL(propose_kernel<1024>, dim3(a.n_steps, a.n_chains), dim3(1024), lds, st, a);
-  else hipLaunchKernelGGL(propose_kernel<512>, dim3(a.n_steps, a.n_chains), dim3(512), lds, st, a);
+  if (wide_table(a)) hipLaunchKernelGGL((propose_kernel<512, 2>), dim3(a.n_steps, a.n_chains), dim3(512), lds, st, a);
+  else if (nt == 1024) hipLaunchKernelGGL((propose_kernel<1024, 1>), dim3(a.n_steps, a.n_chains), dim3(1024), lds, st, a);
+  else hipLaunchKernelGGL((propose_kernel<512, 1>), dim3(a.n_steps, a.n_chains), dim3(512), lds, st, a);
   return hipGetLastError();
 }
 
@@ -208,8 +216,8 @@ hipError_t launch_propose_scalars(const ProposeArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-int propose_max_tiles1_per_wave() { return 2; }
-int propose_max_tiles_per_wave() { return 2; }
+int propose_max_tiles1_per_wave() { return 4; }   // wide instantiation: 32 stage-1 output tiles (64 half-tile units) on 8 waves
+int propose_max_tiles_per_wave() { return 4; }    // 32 stage-2 output tiles
 int propose_waves() { return 8; }
 
 }  // namespace gsm

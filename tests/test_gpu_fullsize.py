@@ -107,8 +107,10 @@ def test_block_as_large_as_the_grid_and_single_chain():
 
 def test_large_blocks_use_the_wider_instantiation():
     """Blocks of 96-110 cells on a 128x128 grid: the step kernel's 12-cells-per-thread instantiation (one workgroup per
-    CU, deep load batching) against the oracle; the spectral proposal kernel refuses such blocks cleanly (its
-    accumulator tiling covers blocks up to about 80x80) while replay keeps working."""
+    CU, deep load batching) against the oracle in replay mode; in Philox mode the wide instantiation of the proposal kernel
+    (32 output tiles per DFT stage) against the Philox restatement, and gsm_run_philox (two-kernel pipeline: the fused kernel
+    does not take such tables) == propose + replay.  Tables whose coefficient planes exceed the LDS are refused cleanly."""
+    import philox_oracle as po
     from gpu_common import oracle_chains, replay_inputs
     from mcmc_gpu_amd._lib import GsmError
     from mcmc_gpu_amd.engine import GsmEngine
@@ -120,14 +122,48 @@ def test_large_blocks_use_the_wider_instantiation():
     eng.set_blocks(pairs, masks)
     eng.set_centres(cfg.region_mask)
     outs = oracle_chains(prob, cfg, pairs, masks, rfp, 2, 60)
-    loss0 = eng.set_state(np.stack([orc.chain_initial_bed(prob, c) for c in range(2)]))
+    beds0 = np.stack([orc.chain_initial_bed(prob, c) for c in range(2)])
+    loss0 = eng.set_state(beds0)
     loss, acc = eng.run_replay(*replay_inputs(eng, outs))
     for c, o in enumerate(outs):
         assert np.array_equal(acc[c], o[4][1:].astype(np.uint8))
         np.testing.assert_allclose(loss[c], o[3][1:], rtol=1e-10)
         assert np.array_equal(eng.beds[c].cpu().numpy(), o[0])
         assert np.array_equal(eng.resampled[c].cpu().numpy().astype(float), o[5])
+    # Philox mode on the same table
     rfp.resolution = prob["resolution"]
-    with pytest.raises(GsmError, match="too large"):
-        eng.propose_philox(2, 0, [1, 2], rfp)
+    seeds = [5, 6]
+    p = eng.propose_philox(12, 40, seeds, rfp)
+    centres = np.flatnonzero(cfg.region_mask.ravel() == 1)
+    shapes = set()
+    for c in range(2):
+        for s in range(12):
+            e = po.proposal(seeds[c], 40 + s, rfp, pairs, masks, centres, 128, prob["resolution"])
+            assert int(p["size_idx"][c, s]) == e["size_idx"] and tuple(p["centre"][c, s].tolist()) == e["centre"]
+            bh, bw = e["field"].shape
+            shapes.add((bh, bw))
+            f = p["fields"][c, s, : bh * bw].cpu().numpy().reshape(bh, bw)
+            np.testing.assert_allclose(f, e["field"], rtol=0, atol=po.field_atol(e))
+    assert max(bh * bw for bh, bw in shapes) >= 104 * 104
+    eng.set_state(beds0)
+    la, aa, ba = eng.run_philox(12, 40, seeds, rfp, batch=5)
+    assert eng.last_run_fused() == 0
+    bed_a = eng.beds.cpu().numpy().copy()
+    eng.set_state(beds0)
+    lr, ar = eng.run_replay(p["size_idx"].cpu().numpy(), p["centre"].cpu().numpy(), p["u"].cpu().numpy(), p["fields"])
+    assert np.array_equal(aa, ar) and np.array_equal(la, lr) and np.array_equal(bed_a, eng.beds.cpu().numpy())
+    eng.close()
+    # 122-126-cell blocks: four coefficient planes of 64 x 80 doubles do not fit 160 KiB
+    prob, cfg, pairs, masks, rfp = orc.standard_setup(128, 128, block_min=122, block_max=126)
+    eng = GsmEngine(128, 128, 1)
+    eng.set_static(cfg.surf, cfg.velx, cfg.vely, cfg.dhdt, cfg.smb, cfg.crf_data_weight, cfg.region_mask,
+                   cfg.mc_region_mask, cfg.resolution, cfg.sigma_mc)
+    rfp.resolution = prob["resolution"]
+    try:
+        eng.set_blocks(pairs, masks)
+        eng.set_centres(cfg.region_mask)
+        with pytest.raises(GsmError, match="too large"):
+            eng.propose_philox(2, 0, [1], rfp)
+    except GsmError as e:           # or already refused by gsm_set_blocks (window larger than the LDS tile)
+        assert "LDS" in str(e)
     eng.close()
