@@ -147,6 +147,7 @@ def launch_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), GSM_DIST_BACKEND=backend, GSM_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("OMP_NUM_THREADS", "1")      # as torchrun does: N ranks must not each start a thread per host core
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env))
     rc = 0
     alive = list(procs)

@@ -178,6 +178,8 @@ def _rank_main(rank, world, port, backend, payload_path, result_path):
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch
     import torch.distributed as dist
+    if 'OMP_NUM_THREADS' not in os.environ:
+        torch.set_num_threads(1)          # as torchrun does for its ranks
     parallel.init_distributed(backend)
     if torch.cuda.is_available():
         torch.cuda.set_device(rank if torch.cuda.device_count() > rank else 0)
