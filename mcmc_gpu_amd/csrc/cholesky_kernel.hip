@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void cz_scalars_kernel(const ProposeArgs a, co
 // one thread: exclusive scans of the per-group proposal counts (records, padded columns, 64-wide tiles)
 __global__ void cz_scan_kernel(const ProposeArgs a, const CholArgs c) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int rec_off = 0, tile_off = 0;
+  int rec_off = 0, tile_off = 0, work_off = 0;
   int64_t z_off = 0;
   for (int g = 0; g < c.n_groups; ++g) {
     const int cnt = c.counts[g];
@@ -130,12 +130,15 @@ __global__ void cz_scan_kernel(const ProposeArgs a, const CholArgs c) {
     c.tile_off[g] = tile_off;
     c.z_off[g] = z_off;
     c.cursor[g] = 0;
+    c.work_off[g] = work_off;
     rec_off += cnt;
     tile_off += ppad >> 6;
+    work_off += (ppad >> 6) * ((N + 63) >> 6);            // 64 x 64 output tiles of this group
     z_off += (int64_t)((N + 63) & ~63) * ppad;
   }
   c.rec_off[c.n_groups] = rec_off;
   c.tile_off[c.n_groups] = tile_off;
+  c.work_off[c.n_groups] = work_off;
 }
 
 __global__ __launch_bounds__(256) void cz_scatter_kernel(const ProposeArgs a, const CholArgs c) {
@@ -197,17 +200,22 @@ __global__ __launch_bounds__(256) void cz_zgen_kernel(const ProposeArgs a, const
 __global__ __launch_bounds__(256) void cz_gemm_kernel(const ProposeArgs a, const CholArgs c) {
   __shared__ double As[2][16][kTS];
   __shared__ double Bs[2][16][kTS];
-  const int tile = blockIdx.x;
-  if (tile >= c.tile_off[c.n_groups]) return;
-  const int g = find_group(c.tile_off, c.n_groups, tile);
+  // Output tiles are enumerated group by group ((block size, range class): one factor U, one Z), n-tile major inside a
+  // group: the workgroups in flight at any time then share one factor (<= 164 MB of its upper half) and one Z (<= 36 MB),
+  // which the Infinity Cache holds -- with a (p-tile, n-tile) grid over all groups every n-tile pass re-read every group's
+  // Z from HBM.
+  const int work = blockIdx.x;
+  if (work >= c.work_off[c.n_groups]) return;
+  const int g = find_group(c.work_off, c.n_groups, work);
   const int cnt = c.counts[g];
   const int ppad = (cnt + 63) & ~63;
   const int si = g / c.n_classes;
   const int N = a.B.bh[si] * a.B.bw[si];
   const int Npad = (N + 63) & ~63;
-  const int n0 = blockIdx.y * 64;
-  if (n0 >= Npad) return;
-  const int p0 = (tile - c.tile_off[g]) * 64;
+  const int n_pt = ppad >> 6;
+  const int idx = work - c.work_off[g];
+  const int n0 = (idx / n_pt) * 64;
+  const int p0 = (idx % n_pt) * 64;
   const double* __restrict__ Z = c.zbuf + c.z_off[g];        // [Npad][ppad]
   const double* __restrict__ U = c.factors[g];               // [Npad][Npad] upper triangular (= L^T), zero padded
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -399,7 +407,7 @@ hipError_t launch_propose_cholesky(const ProposeArgs& a, const CholArgs& c, hipS
   const unsigned max_tiles = (unsigned)((nrec + 63) / 64 + c.n_groups);
   const int nmax = a.B.max_bh * a.B.max_bw;
   hipLaunchKernelGGL(cz_zgen_kernel, dim3(max_tiles, 16), dim3(256), 0, st, a, c);
-  hipLaunchKernelGGL(cz_gemm_kernel, dim3(max_tiles, (unsigned)((nmax + 63) / 64)), dim3(256), 0, st, a, c);
+  hipLaunchKernelGGL(cz_gemm_kernel, dim3(max_tiles * (unsigned)((nmax + 63) / 64)), dim3(256), 0, st, a, c);
   return hipGetLastError();
 }
 
