@@ -86,7 +86,9 @@ struct Win {
   int dr, dc;              // window origin inside the tile (0 or 1)
   uint32_t m_tw;           // magic reciprocal of tw
 };
-__device__ __forceinline__ Win make_win(int H, int W, int row, int col, int bh, int bw) {
+// m_tw: the magic reciprocal of the tile width if the caller has it already (0: compute it -- a uniform 32-bit division,
+// which the compiler does with a float reciprocal on the vector unit and v_readfirstlane)
+__device__ __forceinline__ Win make_win(int H, int W, int row, int col, int bh, int bw, uint32_t m_tw = 0u) {
   Win g;
   g.r0 = max(0, row - bh / 2); g.r1 = min(H, row + bh / 2);
   g.c0 = max(0, col - bw / 2); g.c1 = min(W, col + bw / 2);
@@ -96,7 +98,7 @@ __device__ __forceinline__ Win make_win(int H, int W, int row, int col, int bh, 
   g.hc0 = max(0, g.c0 - 1); g.hc1 = min(W, g.c1 + 1);
   g.tw = g.hc1 - g.hc0;
   g.ncell = (g.hr1 - g.hr0) * g.tw;
-  g.m_tw = magic_for((uint32_t)g.tw);
+  g.m_tw = m_tw ? m_tw : magic_for((uint32_t)g.tw);
   g.dr = g.r0 - g.hr0; g.dc = g.c0 - g.hc0;
   return g;
 }
@@ -119,23 +121,31 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
   const int chain = blockIdx.x;
   const int n_steps = fa.T.n_steps;
-  // buffer descriptors are rebuilt where they are used (a few scalar instructions) rather than held for the whole launch
-  auto plane_off = [&](cargs_t K) { return (size_t)chain * (size_t)K->T.S.H * (size_t)K->T.S.W; };
-  auto n_cells = [&](cargs_t K) { return (uint32_t)K->T.S.H * (uint32_t)K->T.S.W; };
-  auto rsrc_bed = [&](cargs_t K) { return make_rsrc((const TS*)K->T.beds + plane_off(K), n_cells(K) * (uint32_t)sizeof(TS)); };
-  auto rsrc_en = [&](cargs_t K) { return make_rsrc((const TS*)K->T.energy + plane_off(K), n_cells(K) * (uint32_t)sizeof(TS)); };
-  auto rsrc_rs = [&](cargs_t K) { return make_rsrc(K->T.resampled + plane_off(K), n_cells(K) * 4u); };
+  const int gH = fa.T.S.H, gW = fa.T.S.W;
+  // base pointers stay resident (a spilled SGPR comes back with one v_readlane; a reload is a scalar-memory round trip at the
+  // head of the phase); the descriptors themselves (4 SGPRs each) are rebuilt where they are used
+  const TS* const p_bed = (const TS*)fa.T.beds + (size_t)chain * (size_t)fa.T.S.H * (size_t)fa.T.S.W;
+  const TS* const p_en = (const TS*)fa.T.energy + (size_t)chain * (size_t)fa.T.S.H * (size_t)fa.T.S.W;
+  uint32_t* const p_rs = fa.T.resampled + (size_t)chain * (size_t)fa.T.S.H * (size_t)fa.T.S.W;
+  const double2* const p_st = fa.T.S.sA;
+  const double two_res = fa.T.S.two_res, rcp_two_res = fa.T.S.rcp_two_res, two_sigma2 = fa.T.S.two_sigma2;
+  const double rcp_two_sigma2 = fa.T.S.rcp_two_sigma2;
+  auto n_cells = [&](cargs_t) { return (uint32_t)gH * (uint32_t)gW; };
+  auto rsrc_bed = [&](cargs_t K) { return make_rsrc(p_bed, n_cells(K) * (uint32_t)sizeof(TS)); };
+  auto rsrc_en = [&](cargs_t K) { return make_rsrc(p_en, n_cells(K) * (uint32_t)sizeof(TS)); };
+  auto rsrc_rs = [&](cargs_t K) { return make_rsrc(p_rs, n_cells(K) * 4u); };
   // the three packed static operands are one allocation: sA | sB | sC, selected by the scalar offset of the load
-  auto rsrc_st = [&](cargs_t K) { return make_rsrc(K->T.S.sA, 3u * n_cells(K) * 16u); };
+  auto rsrc_st = [&](cargs_t K) { return make_rsrc(p_st, 3u * n_cells(K) * 16u); };
   auto rec_at = [&](cargs_t K, int step) -> crec_t {
     return (crec_t)(uintptr_t)(K->P.scalars + (size_t)chain * K->P.n_steps + step);
   };
   const uint64_t seed = fa.P.seeds[chain];
 
   double s_hi = fa.T.loss_sum[2 * chain], s_lo = fa.T.loss_sum[2 * chain + 1];
-  double loss_prev = (s_hi + s_lo) / fa.T.S.two_sigma2;
+  double loss_prev = (s_hi + s_lo) / two_sigma2;
   // window of the previous step if it was accepted (its stores may still be in flight), else empty.  Older stores
   // are complete: vmcnt counts in order and every thread has since waited for younger loads of its own.
   int pr0 = 0, pr1 = 0, pc0 = 0, pc1 = 0;
@@ -160,7 +170,11 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     int ptid = tid;
     asm volatile("" : "+v"(ptid));
     auto relaunder = [&] { asm volatile("" : "+v"(ptid)); };
-    auto win_of = [&](cargs_t K, crec_t r) { return make_win(K->T.S.H, K->T.S.W, r->row, r->col, r->bh, r->bw); };
+    // The step's record pointer and its four window integers stay in scalar registers for the whole step (a spilled SGPR
+    // costs one v_readlane; re-reading them costs two dependent scalar-memory round trips at the head of every phase).
+    const crec_t rec = rec_at(kargs(), s);
+    const int s_row = rec->row, s_col = rec->col, s_bh = rec->bh, s_bw = rec->bw;
+    auto win_now = [&] { return make_win(gH, gW, s_row, s_col, s_bh, s_bw); };
     auto cell = [&](const Win& G, int W, int k, int& i, int& lr, int& lc, uint32_t& g, bool& valid, bool& inwin) {
       i = ptid + k * kNT;
       valid = i < G.ncell;
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     {
       const cargs_t K = kargs();
       const ProposeArgs pa = load_c(&K->P);
-      const PropScalars q = prop_rec(rec_at(K, s));
+      const PropScalars q = prop_rec(rec);
       const PropGeom pg = prop_geom(pa, q.bh, q.bw);
       dma_to_lds<kNW, 0>(pa.tables + q.fy_off, lds + lds_xh4, 2 * pg.KR * pg.NR, wave, lane);
       dma_to_lds<kNW, 0>(pa.tables + q.g_off, fld, 2 * pg.Kc * pg.M1, wave, lane);
@@ -183,21 +197,32 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     STAMP(10);
     // ---- P0: chain state of the window -> registers, in flight during the two MFMA stages ------------------------------
     double vb[KT], ve[KT];
+    // tile row | tile col << 8 | valid << 16 | in-window << 17 of the thread's cells: computed once per step, here
+    uint32_t rq[KT];
     {
       relaunder();
       const cargs_t K = kargs();
-      const Win G = win_of(K, rec_at(K, s));
+      const Win G = win_now();
       // stores of an earlier accepted step must have landed before this step reads an overlapping halo window
       if ((G.hr0 < pr1) && (pr0 < G.hr1) && (G.hc0 < pc1) && (pc0 < G.hc1)) __syncthreads();
       const rsrc_t r_bed = rsrc_bed(K);
       const rsrc_t r_en = rsrc_en(K);
-      const int W = K->T.S.W;
+      const int W = gW;
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
-        int i, lr, lc; uint32_t g; bool valid, inwin;
-        cell(G, W, k, i, lr, lc, g, valid, inwin);
-        vb[k] = StateIO<TS>::load(r_bed, valid ? g * (uint32_t)sizeof(TS) : kOOB);
-        ve[k] = StateIO<TS>::load(r_en, inwin ? g * (uint32_t)sizeof(TS) : kOOB);
+        // a slot past the end of the tile for the whole wave: no geometry, but the two loads are still issued (out of
+        // range, they return 0) so that the counted wait below holds for every wave
+        if (k * kNT + 64 * wave < G.ncell) {
+          int i, lr, lc; uint32_t g; bool valid, inwin;
+          cell(G, W, k, i, lr, lc, g, valid, inwin);
+          vb[k] = StateIO<TS>::load(r_bed, valid ? g * (uint32_t)sizeof(TS) : kOOB);
+          ve[k] = StateIO<TS>::load(r_en, inwin ? g * (uint32_t)sizeof(TS) : kOOB);
+          rq[k] = (uint32_t)lr | ((uint32_t)lc << 8) | (valid ? 1u << 16 : 0u) | (inwin ? 1u << 17 : 0u);
+        } else {
+          rq[k] = 0;
+          vb[k] = StateIO<TS>::load(r_bed, kOOB);
+          ve[k] = StateIO<TS>::load(r_en, kOOB);
+        }
       }
     }
     STAMP(0);
@@ -212,7 +237,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       {
         const cargs_t K = kargs();
         const ProposeArgs pa = load_c(&K->P);
-        const PropScalars q = prop_rec(rec_at(K, s));
+        const PropScalars q = prop_rec(rec);
         dft_stage1<kNW, kUPW, true>(wave, ptid & 63, pa, q, prop_geom(pa, q.bh, q.bw), lds, lds + lds_xh4, uc, us);
       }
       STAMP(1);
@@ -221,9 +246,8 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       {
         const cargs_t K = kargs();
         const ProposeArgs pa = load_c(&K->P);
-        crec_t r = rec_at(K, s);
         relaunder();
-        dft_tt_write<kNW, kUPW>(wave, ptid & 63, prop_geom(pa, r->bh, r->bw), lds, uc, us);
+        dft_tt_write<kNW, kUPW>(wave, ptid & 63, prop_geom(pa, s_bh, s_bw), lds, uc, us);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -231,7 +255,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     {
       const cargs_t K = kargs();
       const ProposeArgs pa = load_c(&K->P);
-      const PropScalars q = prop_rec(rec_at(K, s));
+      const PropScalars q = prop_rec(rec);
       const PropGeom pg = prop_geom(pa, q.bh, q.bw);
       const int bw = q.bw;
       v4f64 fe[1], fo[1];
@@ -264,7 +288,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     // Geometry for phases A, D and E, computed once per step after the proposal and kept packed in two registers per
     // cell: gq = flat grid index, rq = tile row | tile col << 8 | valid << 16 | in-window << 17 (+1.9 % over recomputing
     // it in every phase, same box).  The arrays are laundered per phase so that only they stay live across phases.
-    uint32_t gq[KT], rq[KT];
+    uint32_t gq[KT];
     auto cellq = [&](int k, int& i, int& lr, int& lc, uint32_t& g, bool& valid, bool& inwin) {
       i = ptid + k * kNT; g = gq[k];
       lr = (int)(rq[k] & 0xFFu); lc = (int)((rq[k] >> 8) & 0xFFu);
@@ -281,17 +305,13 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     double acc_old = 0.0;
     {
       const cargs_t K = kargs();
-      crec_t r = rec_at(K, s);
-      const Win G = win_of(K, r);
-      const int bw = r->bw, W = K->T.S.W;
+      const Win G = win_now();
+      const int bw = s_bw, W = gW;
       const uint32_t off_sB = n_cells(K) * 16u, off_sC = 2u * off_sB;
       auto slot_on = [&](int k) { return k * kNT + 64 * wave < G.ncell; };
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
-        int i, lr, lc; uint32_t g; bool valid, inwin;
-        cell(G, W, k, i, lr, lc, g, valid, inwin);
-        gq[k] = g;
-        rq[k] = (uint32_t)lr | ((uint32_t)lc << 8) | (valid ? 1u << 16 : 0u) | (inwin ? 1u << 17 : 0u);
+        gq[k] = (uint32_t)((G.hr0 + (int)(rq[k] & 0xFFu)) * W + G.hc0 + (int)((rq[k] >> 8) & 0xFFu));
       }
       const rsrc_t r_st = rsrc_st(K);
       constexpr int KB = (KT > 4) ? 2 : KT;      // cells per sub-batch of phase A (2: +0.8 % over 4, same box)
@@ -343,6 +363,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       for (int k = 0; k < KT; ++k) {
         int i, lr, lc; uint32_t g; bool valid, inwin;
         cellq(k, i, lr, lc, g, valid, inwin);
+        if (!slot_on(k)) { C2[k] = make_double2(0.0, 0.0); continue; }
         C2[k] = ld_f64x2(r_st, inwin ? g * 16u : kOOB, off_sC);
       }
     }
@@ -355,10 +376,8 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     double acc_new = 0.0;
     launderq();
     {
-      const cargs_t K = kargs();
-      const StaticFields S = load_c(&K->T.S);
-      const int H = S.H, W = S.W;
-      const Win G = win_of(K, rec_at(K, s));
+      const int H = gH, W = gW;
+      const Win G = win_now();
       const int tw = G.tw, hr0 = G.hr0, hc0 = G.hc0;
       auto slot_on = [&](int k) { return k * kNT + 64 * wave < G.ncell; };
       // interior step (a halo ring on all four sides, ~5 steps in 6): no window cell touches a grid border, every
@@ -377,20 +396,22 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
             if (INTERIOR) {
               const double ddx = qx[i + 1] - qx[i - 1];
               const double ddy = qy[i + tw] - qy[i - tw];
-              if (FAST_DIV) { dx = exact_div(ddx, S.two_res, S.rcp_two_res); dy = exact_div(ddy, S.two_res, S.rcp_two_res); }
-              else { dx = ddx / S.two_res; dy = ddy / S.two_res; }
+              if (FAST_DIV) { dx = exact_div(ddx, two_res, rcp_two_res); dy = exact_div(ddy, two_res, rcp_two_res); }
+              else { dx = ddx / two_res; dy = ddy / two_res; }
             } else {
+              const cargs_t K = kargs();
+              const double res = K->T.S.res, rcp_res = K->T.S.rcp_res;      // border windows only: read where they are needed
               const int r = hr0 + lr, c = hc0 + lc;
               const int il = (c == 0) ? i : i - 1, ir = (c == W - 1) ? i : i + 1;
               const int iu = (r == 0) ? i : i - tw, id = (r == H - 1) ? i : i + tw;
               const double ddx = qx[ir] - qx[il];
               const double ddy = qy[id] - qy[iu];
               if (FAST_DIV) {
-                dx = (ir - il == 2) ? exact_div(ddx, S.two_res, S.rcp_two_res) : exact_div(ddx, S.res, S.rcp_res);
-                dy = (id - iu == 2 * tw) ? exact_div(ddy, S.two_res, S.rcp_two_res) : exact_div(ddy, S.res, S.rcp_res);
+                dx = (ir - il == 2) ? exact_div(ddx, two_res, rcp_two_res) : exact_div(ddx, res, rcp_res);
+                dy = (id - iu == 2 * tw) ? exact_div(ddy, two_res, rcp_two_res) : exact_div(ddy, res, rcp_res);
               } else {
-                dx = ddx / ((ir - il == 2) ? S.two_res : S.res);
-                dy = ddy / ((id - iu == 2 * tw) ? S.two_res : S.res);
+                dx = ddx / ((ir - il == 2) ? two_res : res);
+                dy = ddy / ((id - iu == 2 * tw) ? two_res : res);
               }
             }
             const double v = ((dx + dy) + C2[k].x) - C2[k].y;
@@ -427,16 +448,17 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     two_sum(s_hi, sn - so, c_hi, c_err);
     const double c_lo = s_lo + c_err;
     const cargs_t Ke = kargs();
-    double loss_next = (c_hi + c_lo) / Ke->T.S.two_sigma2;
+    double loss_next = FAST_DIV ? exact_div(c_hi + c_lo, two_sigma2, rcp_two_sigma2) : (c_hi + c_lo) / two_sigma2;
     if (gd > 0.0) loss_next = INFINITY;
-    const double p_acc = (loss_prev > loss_next) ? 1.0 : fmin(1.0, exp(loss_prev - loss_next));
-    crec_t rc = rec_at(Ke, s);
-    const bool acc = (rc->u <= p_acc);
+    // every thread holds the same numbers: a scalar branch skips the exponential of a downhill step
+    double p_acc = 1.0;
+    if (!__builtin_amdgcn_readfirstlane((int)(loss_prev > loss_next))) p_acc = fmin(1.0, exp(loss_prev - loss_next));
+    const bool acc = (rec->u <= p_acc);
 
     // ---- E: commit -------------------------------------------------------------------------------------
     if (acc) {
       launderq();
-      const Win G = win_of(Ke, rc);
+      const Win G = win_now();
       auto slot_on = [&](int k) { return k * kNT + 64 * wave < G.ncell; };
       const rsrc_t r_bed = rsrc_bed(Ke);
       const rsrc_t r_en = rsrc_en(Ke);
@@ -463,7 +485,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       const int64_t rout = (int64_t)chain * a.rec_stride + a.rec_offset + s;
       a.loss[rout] = loss_prev;
       a.accept[rout] = acc ? 1 : 0;
-      if (a.blocks) { a.blocks[4 * rout] = rc->row; a.blocks[4 * rout + 1] = rc->col; a.blocks[4 * rout + 2] = rc->bh; a.blocks[4 * rout + 3] = rc->bw; }
+      if (a.blocks) { a.blocks[4 * rout] = s_row; a.blocks[4 * rout + 1] = s_col; a.blocks[4 * rout + 2] = s_bh; a.blocks[4 * rout + 3] = s_bw; }
     }
   }
   if (tid == 0) {

@@ -178,15 +178,19 @@ extern "C" int gsm_set_static(gsm_handle h, const double* surf, const double* ve
   S.two_res = 2.0 * resolution;
   S.rcp_res = 1.0 / S.res;
   S.rcp_two_res = 1.0 / S.two_res;
+  S.two_sigma2 = 2 * (sigma_mc * sigma_mc);
+  S.rcp_two_sigma2 = 1.0 / S.two_sigma2;
   // exact_div() needs a correctly rounded reciprocal of a divisor whose significand is not all ones and
   // quotients far from the exponent limits; anything else takes the IEEE division path.
   {
-    uint64_t bits;
-    memcpy(&bits, &S.res, sizeof(bits));
-    const bool all_ones = (bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull;
-    S.fast_div = (!all_ones && S.res > 1e-100 && S.res < 1e100) ? 1 : 0;
+    auto divisor_ok = [](double d) {
+      uint64_t bits;
+      memcpy(&bits, &d, sizeof(bits));
+      const bool all_ones = (bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull;
+      return !all_ones && d > 1e-100 && d < 1e100;
+    };
+    S.fast_div = (divisor_ok(S.res) && divisor_ok(S.two_sigma2)) ? 1 : 0;
   }
-  S.two_sigma2 = 2 * (sigma_mc * sigma_mc);
   if (!h->d_svx) {
     HIPCHK(h, hipMalloc(&h->d_svx, n * sizeof(double2)));
     HIPCHK(h, hipMalloc(&h->d_svy, n * sizeof(double2)));

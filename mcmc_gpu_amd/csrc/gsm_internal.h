@@ -31,8 +31,9 @@ struct StaticFields {
   double two_res;         // 2.0 * h  (np.gradient interior denominator)
   double rcp_res;         // RN(1/h), RN(1/(2h)): used when fast_div
   double rcp_two_res;
-  int fast_div;           // 1: x/h as fma-corrected reciprocal multiply (bit-identical to IEEE division)
+  int fast_div;           // 1: x/h and x/(2 sigma^2) as fma-corrected reciprocal multiplies (bit-identical to IEEE division)
   double two_sigma2;      // 2 * sigma_mc**2
+  double rcp_two_sigma2;  // RN(1/(2 sigma^2))
 };
 
 struct BlockTable {
