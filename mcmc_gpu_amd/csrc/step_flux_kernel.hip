@@ -231,27 +231,22 @@ __global__ __launch_bounds__(kNT, 4) void step_flux_kernel(const StepArgs a) {
     STAMP(3);
     // ---- R: reduce, decide (every thread evaluates the same numbers in the same order) ----------------
     {
-      const double w_old = wave64_sum(acc_old);
-      const double w_new = wave64_sum(acc_new);
-      const bool w_guard = __any(guard) != 0;
-      if (lane == 0) {
-        red[wave * 4 + 0] = w_old;
-        red[wave * 4 + 1] = w_new;
-        red[wave * 4 + 2] = w_guard ? 1.0 : 0.0;
-      }
+      // one sum: the thread's change of energy, or +inf from a thread whose candidate grounds the ice (MCMC.py:1321-1329:
+      // loss = inf); energies are never NaN (phase D), so an infinite total can only come from the guard
+      double delta = acc_new - acc_old;
+      if (guard) delta = INFINITY;
+      const double w_delta = wave64_sum(delta);
+      if (lane == 0) red[wave] = w_delta;
     }
     STAMP(4);
     __syncthreads();
     STAMP(5);
-    const int rl = (lane & 15) * 4;
-    const double so = row16_sum(red[rl]);
-    const double sn = row16_sum(red[rl + 1]);
-    const double gd = row16_sum(red[rl + 2]);
+    const double sd = row16_sum(red[lane & 15]);
     double c_hi, c_err;
-    two_sum(s_hi, sn - so, c_hi, c_err);
+    two_sum(s_hi, sd, c_hi, c_err);
     const double c_lo = s_lo + c_err;
     double loss_next = (c_hi + c_lo) / S.two_sigma2;
-    if (gd > 0.0) loss_next = INFINITY;
+    if (sd == INFINITY) loss_next = INFINITY;
     const double p_acc = (loss_prev > loss_next) ? 1.0 : fmin(1.0, exp(loss_prev - loss_next));
     const bool acc = (uu <= p_acc);
 
