@@ -56,7 +56,7 @@ size_t fused_lds_doubles(const FusedArgs& a) {
   return (size_t)fused_work_len(a) + (size_t)fused_fld_len(a) + 4 * kNW + 32 + 16;
 }
 
-static_assert(sizeof(PropScalars) == 104, "PropScalars: 104-byte records, read field by field with scalar loads");
+static_assert(sizeof(PropScalars) == 120, "PropScalars: 120-byte records, read field by field with scalar loads");
 
 // The per-step record (propose_scalars_kernel's output) is read through the constant address space: the address is uniform
 // and the memory is never written by this kernel, so every access is a scalar load.  Each phase re-reads the few fields it
@@ -86,9 +86,9 @@ struct Win {
   int dr, dc;              // window origin inside the tile (0 or 1)
   uint32_t m_tw;           // magic reciprocal of tw
 };
-// m_tw: the magic reciprocal of the tile width if the caller has it already (0: compute it -- a uniform 32-bit division,
-// which the compiler does with a float reciprocal on the vector unit and v_readfirstlane)
-__device__ __forceinline__ Win make_win(int H, int W, int row, int col, int bh, int bw, uint32_t m_tw = 0u) {
+// m_tw: the magic reciprocal of the tile width, from the step's record (computing it here would be a uniform 32-bit
+// division: a float reciprocal on the vector unit, v_readfirstlane and ~20 dependent scalar instructions)
+__device__ __forceinline__ Win make_win(int H, int W, int row, int col, int bh, int bw, uint32_t m_tw) {
   Win g;
   g.r0 = max(0, row - bh / 2); g.r1 = min(H, row + bh / 2);
   g.c0 = max(0, col - bw / 2); g.c1 = min(W, col + bw / 2);
@@ -98,7 +98,7 @@ __device__ __forceinline__ Win make_win(int H, int W, int row, int col, int bh, 
   g.hc0 = max(0, g.c0 - 1); g.hc1 = min(W, g.c1 + 1);
   g.tw = g.hc1 - g.hc0;
   g.ncell = (g.hr1 - g.hr0) * g.tw;
-  g.m_tw = m_tw ? m_tw : magic_for((uint32_t)g.tw);
+  g.m_tw = m_tw;
   g.dr = g.r0 - g.hr0; g.dc = g.c0 - g.hc0;
   return g;
 }
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     PropScalars q;
     q.scale = r->scale; q.nug = r->nug; q.aa = r->aa; q.m_const = r->m_const; q.m_kappa = r->m_kappa;
     q.bh = r->bh; q.bw = r->bw; q.fy_off = r->fy_off; q.g_off = r->g_off; q.pad = r->pad; q.mask_off = r->mask_off;
+    q.m_nc = r->m_nc; q.m_m1 = r->m_m1;
     return q;
   };
   for (int s = 0; s < n_steps; ++s) {
@@ -174,7 +175,8 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     // costs one v_readlane; re-reading them costs two dependent scalar-memory round trips at the head of every phase).
     const crec_t rec = rec_at(kargs(), s);
     const int s_row = rec->row, s_col = rec->col, s_bh = rec->bh, s_bw = rec->bw;
-    auto win_now = [&] { return make_win(gH, gW, s_row, s_col, s_bh, s_bw); };
+    const uint32_t s_mtw = rec->m_tw;
+    auto win_now = [&] { return make_win(gH, gW, s_row, s_col, s_bh, s_bw, s_mtw); };
     auto cell = [&](const Win& G, int W, int k, int& i, int& lr, int& lc, uint32_t& g, bool& valid, bool& inwin) {
       i = ptid + k * kNT;
       valid = i < G.ncell;

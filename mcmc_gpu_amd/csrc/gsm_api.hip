@@ -560,7 +560,7 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
   if (h->use_fused < 0) { const char* v = getenv("GSM_FUSED"); h->use_fused = v ? atoi(v) : 1; }
   h->last_fused = 0;
   if (h->use_fused && rf->generator == GSM_GEN_SPECTRAL) {
-    // Segments of at most kFusedSegment steps: the per-(chain, step) scalar records (104 + 20 bytes) are sized by the
+    // Segments of at most kFusedSegment steps: the per-(chain, step) scalar records (120 + 20 bytes) are sized by the
     // segment, not by the call, and a long call is a sequence of bounded launches on the caller's stream.  Counters are
     // functions of the absolute step, so the split is invisible in the results (test_fused_internal_segments...).
     int seg_cap = kFusedSegment;

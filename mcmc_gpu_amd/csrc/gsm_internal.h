@@ -77,6 +77,9 @@ struct PropScalars {
   int32_t bw, fy_off, g_off, pad;   // block shape and DFT-table offsets: no dependent table look-ups in propose_kernel;
                                     // pad = offset of this shape's k^2 table in ProposeArgs::k2tab
   int64_t mask_off;
+  // magic reciprocals (0xFFFFFFFF / d + 1) of the three divisors of a step -- half-plane columns bw/2 + 1, operand
+  // columns M1, width of the window's halo tile -- so that no workgroup derives them with a uniform division
+  uint32_t m_nc, m_m1, m_tw, reserved;
 };
 
 struct ProposeArgs {

@@ -204,7 +204,7 @@ __device__ __forceinline__ void coef_items(const int t, const int i_lo, const in
   const int SX = g.SX, bh = g.bh, bw = g.bw, hh = g.hh, hw = g.hw, ncol = g.ncol, nrow = g.nrow;
   if (pad) {
     const int npad = g.KR * g.M1;
-    const uint32_t m_m1 = pmagic((uint32_t)g.M1);
+    const uint32_t m_m1 = sc.m_m1;
     for (int i = t; i < npad; i += NTH) {
       const int ky = (int)__umulhi((uint32_t)i, m_m1);
       const int kx = i - ky * g.M1;
@@ -214,7 +214,7 @@ __device__ __forceinline__ void coef_items(const int t, const int i_lo, const in
       }
     }
   }
-  const uint32_t m_nc = pmagic((uint32_t)ncol);
+  const uint32_t m_nc = sc.m_nc;
   const double* __restrict__ k2tab = a.k2tab + sc.pad;          // this shape's [nrow][ncol] table (pad = its offset)
   for (int i = i_lo + t; i < i_hi && !(a.dbg & 32); i += NTH) {
     const double k2 = k2tab[i];                                 // requested first: lands under the Box-Muller code

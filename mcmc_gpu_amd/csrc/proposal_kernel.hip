@@ -56,6 +56,13 @@ __device__ __forceinline__ void block_shape(PropScalars& r, const ProposeArgs& a
   r.fy_off = a.fy_off[r.bh];
   r.g_off = a.g_off[r.bw];
   r.mask_off = a.B.mask_off[r.si];
+  const int ncol = r.bw / 2 + 1;
+  r.m_nc = pmagic((uint32_t)ncol);
+  r.m_m1 = pmagic((uint32_t)((ncol + 15) & ~15));
+  // halo tile of the clipped window (make_win in chain_fused_kernel.hip)
+  const int c0 = max(0, r.col - r.bw / 2), c1 = min(a.W, r.col + r.bw / 2);
+  r.m_tw = pmagic((uint32_t)max(1, min(a.W, c1 + 1) - max(0, c0 - 1)));
+  r.reserved = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
