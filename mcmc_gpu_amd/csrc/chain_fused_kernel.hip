@@ -139,9 +139,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
   auto rsrc_rs = [&](cargs_t K) { return make_rsrc(p_rs, n_cells(K) * 4u); };
   // the three packed static operands are one allocation: sA | sB | sC, selected by the scalar offset of the load
   auto rsrc_st = [&](cargs_t K) { return make_rsrc(p_st, 3u * n_cells(K) * 16u); };
-  auto rec_at = [&](cargs_t K, int step) -> crec_t {
-    return (crec_t)(uintptr_t)(K->P.scalars + (size_t)chain * K->P.n_steps + step);
-  };
+  const crec_t rec0 = (crec_t)(uintptr_t)(fa.P.scalars + (size_t)chain * fa.P.n_steps);   // this chain's records, resident
   const uint64_t seed = fa.P.seeds[chain];
 
   double s_hi = fa.T.loss_sum[2 * chain], s_lo = fa.T.loss_sum[2 * chain + 1];
@@ -173,7 +171,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
     auto relaunder = [&] { asm volatile("" : "+v"(ptid)); };
     // The step's record pointer and its four window integers stay in scalar registers for the whole step (a spilled SGPR
     // costs one v_readlane; re-reading them costs two dependent scalar-memory round trips at the head of every phase).
-    const crec_t rec = rec_at(kargs(), s);
+    const crec_t rec = rec0 + s;
     const int s_row = rec->row, s_col = rec->col, s_bh = rec->bh, s_bw = rec->bw;
     const uint32_t s_mtw = rec->m_tw;
     auto win_now = [&] { return make_win(gH, gW, s_row, s_col, s_bh, s_bw, s_mtw); };
@@ -387,6 +385,8 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       const bool interior = (G.hr0 < G.r0) && (G.hr1 > G.r1) && (G.hc0 < G.c0) && (G.hc1 > G.c1);
       auto phase_d = [&](auto interior_tag) {
         constexpr bool INTERIOR = decltype(interior_tag)::value;
+        double res = 0.0, rcp_res = 0.0;                                   // border windows only: read where they are needed
+        if (!INTERIOR) { const cargs_t K = kargs(); res = K->T.S.res; rcp_res = K->T.S.rcp_res; }
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
           if (!slot_on(k)) { e_new[k] = 0.0; continue; }
@@ -401,8 +401,6 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
               if (FAST_DIV) { dx = exact_div(ddx, two_res, rcp_two_res); dy = exact_div(ddy, two_res, rcp_two_res); }
               else { dx = ddx / two_res; dy = ddy / two_res; }
             } else {
-              const cargs_t K = kargs();
-              const double res = K->T.S.res, rcp_res = K->T.S.rcp_res;      // border windows only: read where they are needed
               const int r = hr0 + lr, c = hc0 + lc;
               const int il = (c == 0) ? i : i - 1, ir = (c == W - 1) ? i : i + 1;
               const int iu = (r == 0) ? i : i - tw, id = (r == H - 1) ? i : i + tw;
