@@ -277,6 +277,23 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       }
     }
     STAMP(12);
+    // static operands of the thread's first phase-A cells: requested before the barrier that phase A begins with
+    // (after it every wave would wait for them at the same time)
+    constexpr int KBA = (KT > 4) ? 2 : KT;
+    double2 A2p[KBA], B2p[KBA];
+    {
+      const cargs_t K = kargs();
+      const Win G = win_now();
+      const rsrc_t r_st = rsrc_st(K);
+      const uint32_t off_sB = n_cells(K) * 16u;
+#pragma unroll
+      for (int j = 0; j < KBA; ++j) {
+        const uint32_t g = (uint32_t)((G.hr0 + (int)(rq[j] & 0xFFu)) * gW + G.hc0 + (int)((rq[j] >> 8) & 0xFFu));
+        const bool valid = (rq[j] >> 16) & 1u;
+        A2p[j] = ld_f64x2(r_st, valid ? g * 16u : kOOB, 0u);
+        B2p[j] = ld_f64x2(r_st, valid ? g * 16u : kOOB, off_sB);
+      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // field tile complete
     STAMP(3);
 
@@ -314,7 +331,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
         gq[k] = (uint32_t)((G.hr0 + (int)(rq[k] & 0xFFu)) * W + G.hc0 + (int)((rq[k] >> 8) & 0xFFu));
       }
       const rsrc_t r_st = rsrc_st(K);
-      constexpr int KB = (KT > 4) ? 2 : KT;      // cells per sub-batch of phase A (2: +0.8 % over 4, same box)
+      constexpr int KB = KBA;                    // cells per sub-batch of phase A (2: +0.8 % over 4, same box)
 #pragma unroll
       for (int kb = 0; kb < KT; kb += KB) {
         if (kb > 0 && !slot_on(kb)) break;   // this wave has no cell in this sub-batch nor in any later one
@@ -326,8 +343,11 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
           if (k < KT) {
             int i, lr, lc; uint32_t g; bool valid, inwin;
             cellq(k, i, lr, lc, g, valid, inwin);
-            A2[j] = ld_f64x2(r_st, valid ? g * 16u : kOOB, 0u);       // (wupd, surf)
-            B2[j] = ld_f64x2(r_st, valid ? g * 16u : kOOB, off_sB);   // (velx, vely)
+            if (kb == 0) { A2[j] = A2p[j]; B2[j] = B2p[j]; }
+            else {
+              A2[j] = ld_f64x2(r_st, valid ? g * 16u : kOOB, 0u);       // (wupd, surf)
+              B2[j] = ld_f64x2(r_st, valid ? g * 16u : kOOB, off_sB);   // (velx, vely)
+            }
             vf[j] = inwin ? fld[(G.mr0 + lr - G.dr) * bw + G.mc0 + lc - G.dc] : 0.0;
           }
         }
