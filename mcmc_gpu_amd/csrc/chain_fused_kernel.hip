@@ -53,7 +53,7 @@ static int fused_work_len(const FusedArgs& a) { return std::max(std::max(2 * a.T
 static int fused_fld_len(const FusedArgs& a) { return std::max(a.T.B.max_bh * a.T.B.max_bw, a.P.tab_max); }
 
 size_t fused_lds_doubles(const FusedArgs& a) {
-  return (size_t)fused_work_len(a) + (size_t)fused_fld_len(a) + 4 * kNW + 32 + 16;
+  return (size_t)fused_work_len(a) + (size_t)fused_fld_len(a) + 4 * kNW + 32 + 16 + kMathTabDoubles;
 }
 
 static_assert(sizeof(PropScalars) == 120, "PropScalars: 120-byte records, read field by field with scalar loads");
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
   double* __restrict__ fld = lds + fa.work_len;                    // [max_bh * max_bw]
   double* __restrict__ red = fld + fa.fld_len;                     // [kNW][4]
   double* __restrict__ red2 = red + 4 * kNW;                       // [32] proposal reductions
+  double* __restrict__ mtab = red2 + 32 + 16;                      // [kMathTabDoubles] log / sincos table (math_tables.h)
   const int lds_xh4 = 4 * fa.P.lds_x_half;                         // the four coefficient planes; the [cos | sin] table follows
 
   const int tid = threadIdx.x;
@@ -141,6 +142,8 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
   auto rsrc_st = [&](cargs_t K) { return make_rsrc(p_st, 3u * n_cells(K) * 16u); };
   const crec_t rec0 = (crec_t)(uintptr_t)(fa.P.scalars + (size_t)chain * fa.P.n_steps);   // this chain's records, resident
   const uint64_t seed = fa.P.seeds[chain];
+  for (int i = tid; i < kMathTabDoubles; i += kNT) mtab[i] = fa.P.mathtab[i];
+  __syncthreads();
 
   double s_hi = fa.T.loss_sum[2 * chain], s_lo = fa.T.loss_sum[2 * chain + 1];
   double loss_prev = (s_hi + s_lo) / two_sigma2;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       const PropGeom pg = prop_geom(pa, q.bh, q.bw);
       dma_to_lds<kNW, 0>(pa.tables + q.fy_off, lds + lds_xh4, 2 * pg.KR * pg.NR, wave, lane);
       dma_to_lds<kNW, 0>(pa.tables + q.g_off, fld, 2 * pg.Kc * pg.M1, wave, lane);
-      coef_items<kNT, false>(ptid, 0, pg.nrow * pg.ncol, true, pa, q, pg, seed, pa.step0 + s, lds, pa.lds_x_half, no_noise);
+      coef_items<kNT, false>(ptid, 0, pg.nrow * pg.ncol, true, pa, q, pg, seed, pa.step0 + s, lds, pa.lds_x_half, no_noise, mtab);
     }
     STAMP(10);
     // ---- P0: chain state of the window -> registers, in flight during the two MFMA stages ------------------------------
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       if (with_nugget) {
         __syncthreads();
         relaunder();
-        nugget_pass<kNT, false>(ptid, pa, q, pg, seed, pa.step0 + s, no_noise, fld, [bw](int y, int x) { return y * bw + x; });
+        nugget_pass<kNT, false>(ptid, pa, q, pg, seed, pa.step0 + s, no_noise, fld, [bw](int y, int x) { return y * bw + x; }, mtab);
       }
     }
     STAMP(12);

@@ -1,5 +1,6 @@
 // C ABI of libgsm_hip.so (see include/gsm.h for the contract and the reference interfaces replaced).
 #include "gsm_internal.h"
+#include "math_tables.h"
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -27,6 +28,7 @@ struct gsm_context {
   int lds_sx = 0, lds_st = 0, lds_x_half = 0, lds_tt = 0, prop_tiles = 0, prop_tiles1 = 0;
   int tables_len = 0, tab_max = 0;
   double* d_k2 = nullptr;        // per-size k^2 tables of the spectral amplitude (depend on rf.resolution)
+  double* d_mathtab = nullptr;   // log / sincos table of the coefficient phase (math_tables.h)
   int32_t* d_k2_off = nullptr;
   double k2_resolution = 0.0;
   PropScalars* d_scalars[2] = {nullptr, nullptr};
@@ -127,6 +129,7 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_g_off) hipFree(h->d_g_off);
   for (auto& p : h->d_scalars) if (p) hipFree(p);
   if (h->d_k2) hipFree(h->d_k2);
+  if (h->d_mathtab) hipFree(h->d_mathtab);
   if (h->d_k2_off) hipFree(h->d_k2_off);
   if (h->d_factors) hipFree(h->d_factors);
   for (auto& c : h->chol) { if (c.ints) hipFree(c.ints); if (c.zoff) hipFree(c.zoff); if (c.per_rec) hipFree(c.per_rec);
@@ -402,7 +405,7 @@ static int check_propose_ready(gsm_handle h, const gsm_rf_params* rf, const char
   if (!(rf->resolution > 0.0)) return fail(h, GSM_E_ARG, std::string(who) + ": rf.resolution must be > 0");
   if (rf->model == GSM_MODEL_MATERN && !(rf->smoothness > 0.0))
     return fail(h, GSM_E_ARG, std::string(who) + ": Matern needs smoothness > 0");
-  const size_t lds = ((size_t)std::max(4 * h->lds_x_half, h->lds_tt) + 64) * 8;
+  const size_t lds = ((size_t)std::max(4 * h->lds_x_half, h->lds_tt) + 64 + kMathTabDoubles) * 8;
   if (lds > 160 * 1024 || h->prop_tiles > propose_max_tiles_per_wave() * propose_waves() ||
       h->prop_tiles1 > propose_max_tiles1_per_wave() * propose_waves())
     return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": block too large for the proposal kernel (LDS / accumulator tiles)");
@@ -411,6 +414,12 @@ static int check_propose_ready(gsm_handle h, const gsm_rf_params* rf, const char
 
 // k^2 tables of the spectral amplitude for this resolution (built on first use, rebuilt when the resolution changes)
 static int ensure_k2(gsm_handle h, const gsm_rf_params* rf, hipStream_t st) {
+  if (rf->generator == GSM_GEN_SPECTRAL && !h->d_mathtab) {      // once per handle: the table of math_tables.h
+    double tab[kMathTabDoubles];
+    build_math_tables(tab);
+    HIPCHK(h, hipMalloc(&h->d_mathtab, sizeof(tab)));
+    HIPCHK(h, hipMemcpy(h->d_mathtab, tab, sizeof(tab), hipMemcpyHostToDevice));
+  }
   if (rf->generator != GSM_GEN_SPECTRAL || h->k2_resolution == rf->resolution) return GSM_OK;
   HIPCHK(h, launch_k2_tables(h->B, h->d_k2_off, rf->resolution, h->d_k2, st));
   h->k2_resolution = rf->resolution;
@@ -452,7 +461,7 @@ static ProposeArgs make_propose(gsm_handle h, const gsm_rf_params* rf, int n_ste
   p.centres = h->d_centres; p.n_centres = h->n_centres;
   p.tables = h->d_tables; p.tables_len = h->tables_len; p.tab_max = h->tab_max; p.fy_off = h->d_fy_off; p.g_off = h->d_g_off;
   p.lds_sx = h->lds_sx; p.lds_st = h->lds_st; p.lds_x_half = h->lds_x_half; p.lds_tt = h->lds_tt;
-  p.k2tab = h->d_k2; p.k2_off = h->d_k2_off;
+  p.k2tab = h->d_k2; p.k2_off = h->d_k2_off; p.mathtab = h->d_mathtab;
   p.lds_main = std::max(4 * h->lds_x_half, h->lds_tt);
   p.tiles1_max = h->prop_tiles1; p.tiles2_max = h->prop_tiles;
   return p;

@@ -106,6 +106,7 @@ struct ProposeArgs {
   int lds_sx, lds_st;      // LDS row strides of X and T^T (== 16 mod 32 doubles: conflict-free fragment reads)
   int lds_x_half;          // doubles per X plane (re or im)
   int lds_tt;              // doubles of T^T
+  const double* mathtab;   // device copy of the table of math_tables.h (kMathTabDoubles doubles)
   int lds_main;            // max(4 * lds_x_half, lds_tt): T^T overlays X
   int tiles1_max, tiles2_max;  // largest stage-1 / stage-2 output-tile counts over the block table
   const double* k2tab;     // (sqrt(kx^2 + ky^2) + 1e-10)^2 on ky <= bh/2, kx <= bw/2, one [nrow][ncol] table per block size

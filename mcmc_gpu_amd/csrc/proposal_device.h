@@ -8,6 +8,7 @@
 #include "gsm_internal.h"
 #include "device_util.h"
 #include "philox.h"
+#include "math_tables.h"
 #include <math.h>
 
 namespace gsm {
@@ -31,37 +32,6 @@ __device__ __forceinline__ double mul_sc(double a, double C) {
   return r;
 }
 
-// log(x) for positive, finite, normal x (here: uniforms in [2^-53, 1] and spectral-density arguments): the fdlibm
-// e_log.c algorithm (argument reduction to [sqrt(1/2), sqrt(2)), s = f / (2 + f), degree-7 minimax in s^2; error
-// < 1 ulp) without the special-case handling and the double-double arithmetic of the library routine -- about half its
-// instructions.  Horner steps are explicit fmas (this file is built with -ffp-contract=off).
-__device__ __forceinline__ double log_pos(double x) {
-  const uint64_t bits = __builtin_bit_cast(uint64_t, x);
-  int k = (int)(bits >> 52) - 1023;
-  uint64_t mant = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;   // m in [1, 2)
-  if ((bits & 0x000FFFFFFFFFFFFFull) >= 0x6A09E667F3BCDull) {                // m >= sqrt(2): halve
-    mant -= 0x0010000000000000ull;
-    k += 1;
-  }
-  const double f = __builtin_bit_cast(double, mant) - 1.0;
-  // s = f / (2 + f), divisor in [1.7, 2.42): reciprocal estimate, two Newton steps, one residual correction
-  const double d = 2.0 + f;
-  double y = __builtin_amdgcn_rcp(d);
-  y = __fma_rn(__fma_rn(-d, y, 1.0), y, y);
-  y = __fma_rn(__fma_rn(-d, y, 1.0), y, y);
-  double s = f * y;
-  s = __fma_rn(__fma_rn(-s, d, f), y, s);
-  const double z = s * s, w = z * z;
-  const double t1 = w * fma_sc(w, fma_sc(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
-                               3.999999999940941908e-01);
-  const double t2 = z * fma_sc(w, fma_sc(w, fma_sc(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
-                                         2.857142874366239149e-01), 6.666666666666735130e-01);
-  const double R = t2 + t1;
-  const double hfsq = 0.5 * f * f;
-  const double dk = (double)k;
-  return mul_sc(dk, 6.93147180369123816490e-01) - ((hfsq - __fma_rn(s, hfsq + R, mul_sc(dk, 1.90821492927058770002e-10))) - f);
-}
-
 // exp(x) for finite x, |x| < 700 (spectral amplitudes): k = rint(x / ln 2), r = x - k ln2_hi - k ln2_lo (|r| <= 0.3466),
 // degree-12 Taylor polynomial of exp(r) (truncation 1.7e-16 relative), scaled by 2^k with v_ldexp_f64 (which also takes
 // care of underflow towards 0).  About half the instructions of the library routine; error < 1.5 ulp.
@@ -83,31 +53,9 @@ __device__ __forceinline__ double exp_lean(double x) {
   return ldexp(p, (int)kf);
 }
 
-// (sin, cos)(2 pi u) for u in [0, 1): quadrant reduction on a = 4u (exact: n = rint(a), f = a - n in [-1/2, 1/2]), then the
-// fdlibm __kernel_sin / __kernel_cos polynomials on x = f pi/2, |x| <= pi/4.  Absolute error < 1.5e-16 (host check against
-// long double over 2e7 arguments); no large-argument reduction, no special cases: about 60 % of the library sincospi.
-__device__ __forceinline__ void sincos_2pi(double u, double& s, double& c) {
-  const double a = 4.0 * u;
-  const double n = __builtin_rint(a);
-  const double x = mul_sc(a - n, 1.57079632679489661923);
-  const double z = x * x;
-  const double ps = fma_sc(z, fma_sc(z, fma_sc(z, fma_sc(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
-                                                2.75573137070700676789e-06), -1.98412698298579493134e-04),
-                           8.33333333332248946124e-03);
-  const double sn = __fma_rn(x * z, fma_sc(z, ps, -1.66666666666666324348e-01), x);
-  const double pc = fma_sc(z, fma_sc(z, fma_sc(z, fma_sc(z, fma_sc(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
-                                                          -2.75573143513906633035e-07), 2.48015872894767294178e-05),
-                                    -1.38888888888741095749e-03), 4.16666666666666019037e-02);
-  const double hz = 0.5 * z, w = 1.0 - hz;
-  const double cs = w + (((1.0 - w) - hz) + z * (z * pc));
-  const int q = (int)n;                    // 0..4
-  const double ss = (q & 1) ? cs : sn, cc = (q & 1) ? sn : cs;
-  s = (q & 2) ? -ss : ss;
-  c = ((q + 1) & 2) ? -cc : cc;
-}
-
+// mt: the table of math_tables.h, in LDS
 __device__ __forceinline__ void normals2(uint64_t seed, int64_t step, uint32_t stream, uint32_t idx, double& g1,
-                                         double& g2) {
+                                         double& g2, const double* mt) {
   // The 20 round keys are uniform functions of the seed: left alone, the compiler computes them once per kernel and
   // holds 20 SGPRs for ever (spilled to VGPR lanes and read back with v_readlane, a vector instruction, at every use).
   // Laundering the seed here makes them 20 scalar adds per call instead.
@@ -116,9 +64,9 @@ __device__ __forceinline__ void normals2(uint64_t seed, int64_t step, uint32_t s
   const u32x4 r = philox_draw(((uint64_t)k1 << 32) | k0, step, stream, idx);
   const double u1 = u01_open0_from(r.x, r.y);
   const double u2 = u01_from(r.z, r.w);
-  const double rad = sqrt(-2.0 * log_pos(u1));
+  const double rad = sqrt(-2.0 * log_tab(u1, mt));
   double s, c;
-  sincos_2pi(u2, s, c);
+  sincos_tab(u2, mt, s, c);
   g1 = rad * c;
   g2 = rad * s;
 }
@@ -136,11 +84,11 @@ __device__ __forceinline__ double wavenumber(int k, int n, double inv) {
 //   Exponential  sqrt((1 + (a k)^2)^-1.5)           = exp(-0.75 log(1 + (a k)^2))
 //   Matern       sqrt(C (kappa + 4 pi k^2)^(-nu-1)) = exp(log(C) / 2 - (nu + 1) / 2 * log(kappa + 4 pi k^2))
 // sc.m_const holds log(C) / 2 (propose_scalars_kernel).  Same values as the reference's formula to a few ulp.
-__device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const PropScalars& sc, const double k2) {
+__device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const PropScalars& sc, const double k2, const double* mt) {
   if (P.model == GSM_MODEL_GAUSSIAN) return exp_lean(-0.25 * ((sc.aa * sc.aa) * k2));
-  if (P.model == GSM_MODEL_EXPONENTIAL) return exp_lean(-0.75 * log_pos(1.0 + (sc.aa * sc.aa) * k2));
+  if (P.model == GSM_MODEL_EXPONENTIAL) return exp_lean(-0.75 * log_tab(1.0 + (sc.aa * sc.aa) * k2, mt));
   const double nu = (P.smoothness != 0.0) ? P.smoothness : 1.0;
-  return exp_lean(__fma_rn(-0.5 * (nu + 1.0), log_pos(sc.m_kappa + 4.0 * M_PI * k2), sc.m_const));
+  return exp_lean(__fma_rn(-0.5 * (nu + 1.0), log_tab(sc.m_kappa + 4.0 * M_PI * k2, mt), sc.m_const));
 }
 
 // DFT folding used below (n even, h = n/2).  With P[k] = X[k] + X[n-k], M[k] = X[k] - X[n-k] (0 < k < h; P = X, M = 0
@@ -196,7 +144,7 @@ __device__ __forceinline__ PropGeom prop_geom(const ProposeArgs& a, int bh, int 
 template <int NTH, bool NOISE_IN>
 __device__ __forceinline__ void coef_items(const int t, const int i_lo, const int i_hi, const bool pad, const ProposeArgs& a,
                                            const PropScalars& sc, const PropGeom& g, const uint64_t seed, const int64_t step,
-                                           double* __restrict__ Pr, const int plane, const NoiseIn noise) {
+                                           double* __restrict__ Pr, const int plane, const NoiseIn noise, const double* mt) {
   const gsm_rf_params& P = a.rf;
   double* __restrict__ Pi = Pr + plane;
   double* __restrict__ Mr = Pi + plane;
@@ -225,7 +173,7 @@ __device__ __forceinline__ void coef_items(const int t, const int i_lo, const in
     double amp, g1 = 0.0, g2 = 0.0, h1 = 0.0, h2 = 0.0;
     double ar, ai, br = 0.0, bi = 0.0;   // X[ky], X[bh - ky]
     if (NOISE_IN) {
-      amp = spectral_amp(P, sc, k2);
+      amp = spectral_amp(P, sc, k2, mt);
       const int nky = (ky == 0) ? 0 : kyc, nkx = (kx == 0) ? 0 : bw - kx;      // -k modulo the block shape
       ar = amp * (0.5 * (noise.re[ky * bw + kx] + noise.re[nky * bw + nkx]));
       ai = amp * (0.5 * (noise.im[ky * bw + kx] - noise.im[nky * bw + nkx]));
@@ -236,12 +184,12 @@ __device__ __forceinline__ void coef_items(const int t, const int i_lo, const in
     } else {
       if (a.dbg & 1) { amp = 1.0; g1 = ky; g2 = kx; h1 = 1.0; h2 = 2.0; }
       else {
-        normals2(seed, step, kStreamSpectrum, (uint32_t)(ky * ncol + kx), g1, g2);
+        normals2(seed, step, kStreamSpectrum, (uint32_t)(ky * ncol + kx), g1, g2, mt);
         // drawn unconditionally (counter-based: an unused draw costs nothing downstream): one straight-line block for
         // both Box-Muller evaluations, so the two chains interleave
-        normals2(seed, step, kStreamSpectrum, (uint32_t)(kyc * ncol + kx), h1, h2);
+        normals2(seed, step, kStreamSpectrum, (uint32_t)(kyc * ncol + kx), h1, h2, mt);
         if (!paired) { h1 = 0.0; h2 = 0.0; }
-        amp = spectral_amp(P, sc, k2);
+        amp = spectral_amp(P, sc, k2, mt);
       }
       if (kx > 0 && kx < hw) {
         ar = amp * (g1 * M_SQRT1_2); ai = amp * (g2 * M_SQRT1_2);
@@ -512,7 +460,7 @@ __device__ __forceinline__ void emit_field(const int w, const int lane, const Pr
 template <int NTH, bool NOISE_IN, class OMap>
 __device__ __forceinline__ void nugget_pass(const int t, const ProposeArgs& a, const PropScalars& sc, const PropGeom& g,
                                             const uint64_t seed, const int64_t step, const NoiseIn noise,
-                                            double* __restrict__ out, OMap omap) {
+                                            double* __restrict__ out, OMap omap, const double* mt) {
   const double* __restrict__ mask = a.B.masks + sc.mask_off;
   const int bw = g.bw, ncell = g.bh * g.bw;
   const double sq_nug = sqrt(sc.nug);
@@ -521,7 +469,7 @@ __device__ __forceinline__ void nugget_pass(const int t, const ProposeArgs& a, c
     const int o = 2 * pr;
     if (NOISE_IN) { n1 = noise.nug[o]; n2 = noise.nug[o + 1]; }
     else {
-      normals2(seed, step, kStreamNugget, (uint32_t)pr, n1, n2);
+      normals2(seed, step, kStreamNugget, (uint32_t)pr, n1, n2, mt);
       n1 *= sq_nug; n2 *= sq_nug;
     }
     const int y = o / bw, x = o - y * bw;       // bw is even: the pair (o, o + 1) lies in one row
@@ -532,7 +480,7 @@ __device__ __forceinline__ void nugget_pass(const int t, const ProposeArgs& a, c
 }
 
 // ---- all stages in turn, by all NT threads of the workgroup (stand-alone kernels) ------------------------------------
-// plds: LDS work area of a.lds_main doubles; red: 32 doubles of LDS.  Contains workgroup barriers: every thread must call
+// plds: LDS work area of a.lds_main doubles; red: 32 + kMathTabDoubles doubles of LDS (reductions, math table).  Contains workgroup barriers: every thread must call
 // it with the same (uniform) arguments.  On return other waves may still be reading `red`.
 // WIDE = 2: twice the output tiles per wave (32 stage-2 tiles, 64 stage-1 units) for block tables beyond ~80 x 80.
 template <int NT, bool NOISE_IN = false, int WIDE = 1, class OMap>
@@ -543,7 +491,10 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const PropGeom g = prop_geom(a, sc.bh, sc.bw);
-  coef_items<NT, NOISE_IN>(tid, 0, g.nrow * g.ncol, true, a, sc, g, seed, step, plds, a.lds_x_half, noise);
+  double* mt = red + 32;                      // [kMathTabDoubles] math_tables.h
+  for (int i = tid; i < kMathTabDoubles; i += NT) mt[i] = a.mathtab[i];
+  __syncthreads();
+  coef_items<NT, NOISE_IN>(tid, 0, g.nrow * g.ncol, true, a, sc, g, seed, step, plds, a.lds_x_half, noise, mt);
   __syncthreads();
   // Mean of the field (MCMC.py:248 subtracts it): every non-DC term of the inverse DFT sums to zero over the block, so
   // mean = X[0][0] / (bh bw) with X[0][0] = Pr[0] (real: its own conjugate partner).  Read before T^T overlays the plane.
@@ -562,7 +513,7 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
   emit_field<NW, MAXT, false>(wave, lane, a, sc, g, fe, fo, mreg, mean, gain, with_nugget, out, omap);
   if (with_nugget) {
     __syncthreads();
-    nugget_pass<NT, NOISE_IN>(tid, a, sc, g, seed, step, noise, out, omap);
+    nugget_pass<NT, NOISE_IN>(tid, a, sc, g, seed, step, noise, out, omap, mt);
   }
 }
 

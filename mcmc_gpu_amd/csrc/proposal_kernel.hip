@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void propose_scalars_kernel(const ProposeArgs 
 template <int NT, int WIDE>
 __global__ __launch_bounds__(NT, (WIDE == 1) ? NT / 256 : 1) void propose_kernel(const ProposeArgs a) {
   extern __shared__ double plds[];
-  double* red = plds + a.lds_main;         // [32]
+  double* red = plds + a.lds_main;         // [32] reductions + [kMathTabDoubles] math table
   const int s = blockIdx.x, chain = blockIdx.y;
   const int64_t rec = (int64_t)chain * a.n_steps + s;
   const PropScalars sc = a.scalars[rec];
@@ -179,7 +179,7 @@ static bool wide_table(const ProposeArgs& a) { return a.tiles2_max > 16 || a.til
 
 hipError_t launch_spectral_from_noise(const ProposeArgs& a, const int32_t* size_idx, const double* rf_scalars,
                                       const double* noise_re, const double* noise_im, const double* nugget_field, hipStream_t st) {
-  const size_t lds = ((size_t)a.lds_main + 32) * sizeof(double);
+  const size_t lds = ((size_t)a.lds_main + 32 + kMathTabDoubles) * sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
@@ -197,7 +197,7 @@ hipError_t launch_spectral_from_noise(const ProposeArgs& a, const int32_t* size_
 hipError_t launch_propose(const ProposeArgs& a_in, hipStream_t st) {
   ProposeArgs a = a_in;
   { static int dbg = -1; if (dbg < 0) { const char* v = getenv("GSM_PROPOSE_DBG"); dbg = v ? atoi(v) : 0; } a.dbg = dbg; }
-  const size_t lds = ((size_t)a.lds_main + 32) * sizeof(double);
+  const size_t lds = ((size_t)a.lds_main + 32 + kMathTabDoubles) * sizeof(double);
   static int nt = -1;   // GSM_PROPOSE_NT=1024: the fused kernel's workgroup size (tests: bit-identical fields)
   if (nt < 0) { const char* v = getenv("GSM_PROPOSE_NT"); nt = (v && atoi(v) == 1024) ? 1024 : 512; }
   static bool attr_set = false;
