@@ -116,6 +116,17 @@ __device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const Pro
 struct NoiseIn { const double* re; const double* im; const double* nug; };
 
 // shape-derived sizes of one proposal (the host builds the tables with the same formulas)
+// t / d for a tile index t < 64 and a tile-grid dimension d (in [1, 8] for every square table) without a division (a uniform integer division costs a
+// float reciprocal on the vector unit, v_readfirstlane and ~20 dependent scalar instructions -- at the head of six stages
+// of every step): q = (t * (2^15 / d + 1)) >> 15, the eight multipliers packed in two 64-bit constants.
+__device__ __forceinline__ uint32_t tile_magic(int d) {
+  const uint64_t lo = 32769ull | (16385ull << 16) | (10923ull << 32) | (8193ull << 48);     // d = 1 .. 4
+  const uint64_t hi = 6554ull | (5462ull << 16) | (4682ull << 32) | (4097ull << 48);        // d = 5 .. 8
+  if (d > 8) return 32768u / (uint32_t)d + 1u;      // elongated block tables only (up to 32 tiles along one side)
+  return (uint32_t)(((d <= 4) ? lo : hi) >> (16 * ((d - 1) & 3))) & 0xFFFFu;
+}
+__device__ __forceinline__ int tile_div(int t, uint32_t magic) { return (int)(((uint32_t)t * magic) >> 15); }
+
 struct PropGeom {
   int bh, bw, hh, hw, ncol, nrow;
   int KR;   // stage-1 K  (ky <= hh), multiple of 4
@@ -124,6 +135,7 @@ struct PropGeom {
   int Kc;   // stage-2 K per half (re | im rows of T^T), multiple of 4
   int N1;   // stage-2 M  (y), multiple of 16
   int SX, ST;
+  uint32_t q_mt, q_mt2;   // tile_magic of M1 / 16 (stage-1 tile columns) and N1 / 16 (stage-2 tile rows)
 };
 __device__ __forceinline__ PropGeom prop_geom(const ProposeArgs& a, int bh, int bw) {
   PropGeom g;
@@ -133,6 +145,7 @@ __device__ __forceinline__ PropGeom prop_geom(const ProposeArgs& a, int bh, int 
   g.M1 = (g.ncol + 15) & ~15; g.Kc = (g.ncol + 3) & ~3;
   g.N1 = (bh + 15) & ~15;
   g.SX = a.lds_sx; g.ST = a.lds_st;
+  g.q_mt = tile_magic(g.M1 >> 4); g.q_mt2 = tile_magic(g.N1 >> 4);
   return g;
 }
 
@@ -239,7 +252,7 @@ __device__ __forceinline__ void dft_stage1(const int w, const int lane, const Pr
     const int u = w + j * NW;
     const int t = u >> 1;
     if (t < n_t1 && !(a.dbg & 2)) {
-      const int mt = t % n_mt, nt = t / n_mt;
+      const int nt = tile_div(t, g.q_mt), mt = t - nt * n_mt;
       const int ao = l4 * SX + 16 * mt + l15;
       const double* __restrict__ Ac = (u & 1) ? Pi : Pr;
       const double* __restrict__ As = (u & 1) ? Mr : Mi;
@@ -275,7 +288,7 @@ __device__ __forceinline__ void dft_tt_write(const int w, const int lane, const 
     const int u = w + j * NW;
     const int t = u >> 1;
     if (t < n_t1) {
-      const int mt = t % n_mt, nt = t / n_mt;
+      const int nt = tile_div(t, g.q_mt), mt = t - nt * n_mt;
       const int y = 16 * nt + l15;
       if (y <= hh) {
         double* __restrict__ Th = TT + ((u & 1) ? Kc * ST : 0);   // real rows, then imaginary rows
@@ -308,7 +321,7 @@ __device__ __forceinline__ void dft_stage2(const int w, const int lane, const Pr
     v4f64 ae = {0.0, 0.0, 0.0, 0.0}, ao = ae;
     const int t = w + j * NW;
     if (t < n_t2 && !(a.dbg & 4)) {
-      const int mt = t % n_mt2, nt = t / n_mt2;
+      const int nt = tile_div(t, g.q_mt2), mt = t - nt * n_mt2;
       const double* a_p = TT + l4 * ST + 16 * mt + l15;
       const double* gc_p = GC + l4 * M1 + 16 * nt + l15;
       const double* gs_p = GS + l4 * M1 + 16 * nt + l15;
@@ -340,7 +353,7 @@ __device__ __forceinline__ void mask_prefetch(const int w, const int lane, const
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
     const int t = w + j * NW;
-    const int mt = t % n_mt2, nt = t / n_mt2;
+    const int nt = tile_div(t, g.q_mt2), mt = t - nt * n_mt2;
     const int x = 16 * nt + l15;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -393,7 +406,7 @@ __device__ __forceinline__ double standardise(const int w, const int lane, const
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
     const int t = w + j * NW;
-    const int mt = t % n_mt2, nt = t / n_mt2;
+    const int nt = tile_div(t, g.q_mt2), mt = t - nt * n_mt2;
     const int x = 16 * nt + l15;
     double p = 0.0;
 #pragma unroll
@@ -436,7 +449,7 @@ __device__ __forceinline__ void emit_field(const int w, const int lane, const Pr
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
     const int t = w + j * NW;
-    const int mt = t % n_mt2, nt = t / n_mt2;
+    const int nt = tile_div(t, g.q_mt2), mt = t - nt * n_mt2;
     const int x = 16 * nt + l15;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
