@@ -130,14 +130,12 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
   // head of the phase); the descriptors themselves (4 SGPRs each) are rebuilt where they are used
   const TS* const p_bed = (const TS*)fa.T.beds + (size_t)chain * (size_t)fa.T.S.H * (size_t)fa.T.S.W;
   const TS* const p_en = (const TS*)fa.T.energy + (size_t)chain * (size_t)fa.T.S.H * (size_t)fa.T.S.W;
-  uint32_t* const p_rs = fa.T.resampled + (size_t)chain * (size_t)fa.T.S.H * (size_t)fa.T.S.W;
   const double2* const p_st = fa.T.S.sA;
   const double two_res = fa.T.S.two_res, rcp_two_res = fa.T.S.rcp_two_res, two_sigma2 = fa.T.S.two_sigma2;
   const double rcp_two_sigma2 = fa.T.S.rcp_two_sigma2;
   auto n_cells = [&](cargs_t) { return (uint32_t)gH * (uint32_t)gW; };
   auto rsrc_bed = [&](cargs_t K) { return make_rsrc(p_bed, n_cells(K) * (uint32_t)sizeof(TS)); };
   auto rsrc_en = [&](cargs_t K) { return make_rsrc(p_en, n_cells(K) * (uint32_t)sizeof(TS)); };
-  auto rsrc_rs = [&](cargs_t K) { return make_rsrc(p_rs, n_cells(K) * 4u); };
   // the three packed static operands are one allocation: sA | sB | sC, selected by the scalar offset of the load
   auto rsrc_st = [&](cargs_t K) { return make_rsrc(p_st, 3u * n_cells(K) * 16u); };
   const crec_t rec0 = (crec_t)(uintptr_t)(fa.P.scalars + (size_t)chain * fa.P.n_steps);   // this chain's records, resident
@@ -480,7 +478,6 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       auto slot_on = [&](int k) { return k * kNT + 64 * wave < G.ncell; };
       const rsrc_t r_bed = rsrc_bed(Ke);
       const rsrc_t r_en = rsrc_en(Ke);
-      const rsrc_t r_rs = rsrc_rs(Ke);
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         if (!slot_on(k)) continue;
@@ -489,7 +486,6 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
         const bool upd = (upd_bits >> k) & 1u;
         StateIO<TS>::store(r_en, inwin ? g * (uint32_t)sizeof(TS) : kOOB, e_new[k]);
         StateIO<TS>::store(r_bed, upd ? g * (uint32_t)sizeof(TS) : kOOB, v_new[k]);
-        __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, r_rs, (int)(upd ? g * 4u : kOOB), 0, 0);
       }
       two_sum(c_hi, c_lo, s_hi, s_lo);
       loss_prev = loss_next;
@@ -546,6 +542,90 @@ bool fused_supported(const FusedArgs& a) {
          2 * a.P.tiles1_max <= kNW * kUPW && a.P.tiles2_max <= 16;
 }
 
+// ---- resampled counts of a launch (MCMC.py:1347 resampled_times[window] += update_mask on every accepted step) ------------
+// The chain kernel does not touch `resampled`: per-cell atomics on lines that live in HBM sit in the in-order vector-memory
+// pipeline of the CU for a memory latency (+1.9 % without them).  The counts of a launch follow from its records and accept
+// flags alone: cell (r, c) gains the number of accepted steps whose window covers it.  One workgroup per (chain, band of
+// rows, tile of columns): every accepted window adds +1 / -1 at its first / past-the-last column in each of its rows of the
+// band (LDS atomics), a running sum along each row turns that into counts, and the counts are added to the plane where
+// update_mask is set.  Integer arithmetic: the same numbers as one atomic per accepted step and cell.
+constexpr int kRsThreads = 256, kRsColTile = 1024, kRsSeg = 64;
+__global__ __launch_bounds__(kRsThreads) void resampled_from_records_kernel(const FusedArgs fa, const int band_rows) {
+  extern __shared__ int cnt[];                 // [band_rows][wt + 1] differences -> counts, then [band_rows][n_seg] segment totals
+  const int chain = blockIdx.x, band0 = blockIdx.y * band_rows, col0 = blockIdx.z * kRsColTile;
+  const int H = fa.T.S.H, W = fa.T.S.W;
+  const int band1 = min(H, band0 + band_rows), col1 = min(W, col0 + kRsColTile);
+  const int wt = col1 - col0, ld = wt + 1, nb = band1 - band0, n_seg = (wt + kRsSeg - 1) / kRsSeg;
+  int* __restrict__ seg_tot = cnt + band_rows * (min(W, kRsColTile) + 1);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nb * ld; i += kRsThreads) cnt[i] = 0;
+  __syncthreads();
+  // one thread per step of the launch
+  const PropScalars* __restrict__ recs = fa.P.scalars + (size_t)chain * fa.P.n_steps;
+  const uint8_t* __restrict__ acc = fa.T.accept + (int64_t)chain * fa.T.rec_stride + fa.T.rec_offset;
+  for (int s = tid; s < fa.T.n_steps; s += kRsThreads) {
+    if (!acc[s]) continue;
+    const int row = recs[s].row, col = recs[s].col, bh = recs[s].bh, bw = recs[s].bw;
+    const int r0 = max(band0, max(0, row - bh / 2)), r1 = min(band1, min(H, row + bh / 2));   // window rows within the band
+    const int c0 = max(col0, max(0, col - bw / 2)), c1 = min(col1, min(W, col + bw / 2));
+    if (c0 >= c1) continue;
+    for (int r = r0; r < r1; ++r) {
+      atomicAdd(&cnt[(r - band0) * ld + (c0 - col0)], 1);
+      atomicAdd(&cnt[(r - band0) * ld + (c1 - col0)], -1);
+    }
+  }
+  __syncthreads();
+  // running sums: one thread per (row, 64-column segment), consecutive threads on consecutive rows (row stride wt + 1 words)
+  for (int t = tid; t < nb * n_seg; t += kRsThreads) {
+    const int sg = t / nb, r = t - sg * nb;
+    const int c_lo = sg * kRsSeg, c_hi = min(wt, c_lo + kRsSeg);
+    int run = 0;
+    for (int c = c_lo; c < c_hi; ++c) { run += cnt[r * ld + c]; cnt[r * ld + c] = run; }
+    seg_tot[r * n_seg + sg] = run;
+  }
+  __syncthreads();
+  uint32_t* __restrict__ plane = fa.T.resampled + (size_t)chain * H * W;
+  const uint8_t* __restrict__ upd = fa.T.S.upd;
+  auto count_at = [&](int r, int c) {
+    int n = cnt[r * ld + c];
+    for (int sg = 0; sg < c / kRsSeg; ++sg) n += seg_tot[r * n_seg + sg];
+    return n;
+  };
+  if ((W & 3) == 0) {                          // four cells per thread and pass: 16-byte loads and stores
+    const int wq = wt >> 2;
+    for (int i = tid; i < nb * wq; i += kRsThreads) {
+      const int r = i / wq, c = (i - r * wq) * 4;
+      const size_t g = (size_t)(band0 + r) * W + col0 + c;
+      const int base = count_at(r, c) - cnt[r * ld + c];        // segment offset (c .. c + 3 lie in one segment)
+      const uchar4 m = *(const uchar4*)(upd + g);
+      const int n0 = m.x ? base + cnt[r * ld + c] : 0, n1 = m.y ? base + cnt[r * ld + c + 1] : 0;
+      const int n2 = m.z ? base + cnt[r * ld + c + 2] : 0, n3 = m.w ? base + cnt[r * ld + c + 3] : 0;
+      if ((n0 | n1 | n2 | n3) == 0) continue;
+      uint4 v = *(uint4*)(plane + g);
+      v.x += (uint32_t)n0; v.y += (uint32_t)n1; v.z += (uint32_t)n2; v.w += (uint32_t)n3;
+      *(uint4*)(plane + g) = v;
+    }
+  } else {
+    for (int i = tid; i < nb * wt; i += kRsThreads) {
+      const int r = i / wt, c = i - r * wt;
+      const int n = count_at(r, c);
+      const size_t g = (size_t)(band0 + r) * W + col0 + c;
+      if (n != 0 && upd[g]) plane[g] += (uint32_t)n;
+    }
+  }
+}
+
+static hipError_t launch_resampled_from_records(const FusedArgs& a, hipStream_t st) {
+  const int W = a.T.S.W, H = a.T.S.H;
+  const int wt = std::min(W, kRsColTile);
+  // ~32 KiB of LDS per workgroup: several workgroups per CU hide each other's memory latency
+  const int band_rows = std::max(1, std::min(H, (int)((32 * 1024 / sizeof(int)) / (size_t)(wt + 1))));
+  const dim3 grid(a.T.n_chains, (H + band_rows - 1) / band_rows, (W + kRsColTile - 1) / kRsColTile);
+  const size_t lds = (size_t)band_rows * (size_t)(wt + 1 + (wt + kRsSeg - 1) / kRsSeg) * sizeof(int);
+  hipLaunchKernelGGL(resampled_from_records_kernel, grid, dim3(kRsThreads), lds, st, a, band_rows);
+  return hipGetLastError();
+}
+
 // One launch: propose_scalars_kernel for all steps must have filled a.P.scalars (n_chains x a.P.n_steps records).
 hipError_t launch_chain_fused(const FusedArgs& a_in, hipStream_t st) {
   if (!fused_supported(a_in)) return hipErrorInvalidValue;
@@ -553,14 +633,18 @@ hipError_t launch_chain_fused(const FusedArgs& a_in, hipStream_t st) {
   { static int dbg = -1; if (dbg < 0) { const char* v = getenv("GSM_PROPOSE_DBG"); dbg = v ? atoi(v) : 0; } a.P.dbg = dbg; }   // diagnostics only
   a.work_len = fused_work_len(a);
   a.fld_len = fused_fld_len(a);
+  hipError_t e;
   if (a.T.f32_state) {
-    if (a.T.tile_cap <= 2 * kNT) return launch_fused_t<float, 2>(a, st);
-    if (a.T.tile_cap <= 4 * kNT) return launch_fused_t<float, 4>(a, st);
-    return launch_fused_t<float, 7>(a, st);
+    if (a.T.tile_cap <= 2 * kNT) e = launch_fused_t<float, 2>(a, st);
+    else if (a.T.tile_cap <= 4 * kNT) e = launch_fused_t<float, 4>(a, st);
+    else e = launch_fused_t<float, 7>(a, st);
+  } else {
+    if (a.T.tile_cap <= 2 * kNT) e = launch_fused_t<double, 2>(a, st);
+    else if (a.T.tile_cap <= 4 * kNT) e = launch_fused_t<double, 4>(a, st);
+    else e = launch_fused_t<double, 7>(a, st);
   }
-  if (a.T.tile_cap <= 2 * kNT) return launch_fused_t<double, 2>(a, st);
-  if (a.T.tile_cap <= 4 * kNT) return launch_fused_t<double, 4>(a, st);
-  return launch_fused_t<double, 7>(a, st);
+  if (e != hipSuccess) return e;
+  return launch_resampled_from_records(a, st);      // the launch's accept flags and records -> resampled counts
 }
 
 }  // namespace gsm
