@@ -276,6 +276,11 @@ int gsm_debug_stamps(uint64_t* out, int32_t n_chains);
 /* Same for the fused chain kernel (16 x uint64 per chain). */
 int gsm_debug_stamps_fused(uint64_t* out, int32_t n_chains);
 
+/* Test hook: the device's standard-normal pairs (Philox4x32-10 counters (idx, stream, step), Box-Muller with the table-driven
+ * log / sincos of the coefficient phase) for idx = idx0 .. idx0 + n - 1: out[2 i], out[2 i + 1] [dev].  Checked against
+ * oracle/philox_oracle.normals2 (numpy log / sqrt / cos / sin). */
+int gsm_debug_normals(uint64_t seed, int64_t step, uint32_t stream_id, uint32_t idx0, int32_t n, double* out, void* stream);
+
 /* Test hook: one Philox4x32-10 block on the host (ctr[4], key[2] -> out[4]); the device generator uses
  * the same inline function.  Checked against the Random123 known-answer vectors. */
 int gsm_philox_selftest(const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4);

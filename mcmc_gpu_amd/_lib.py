@@ -173,6 +173,7 @@ def load() -> C.CDLL:
     lib.gsm_sgs_commit.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.gsm_min_dist_from_mask.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.gsm_debug_stream_copy.argtypes = [vp, vp, i64, vp]
+    lib.gsm_debug_normals.argtypes = [C.c_uint64, i64, C.c_uint32, C.c_uint32, i32, vp, vp]
     lib.gsm_philox_selftest.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     for name in declared_symbols():
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch

@@ -716,6 +716,20 @@ extern "C" int gsm_debug_stamps_fused(uint64_t* out, int32_t n_chains) {
   return debug_read_stamps_fused((unsigned long long*)out, n_chains);
 }
 
+extern "C" int gsm_debug_normals(uint64_t seed, int64_t step, uint32_t stream_id, uint32_t idx0, int32_t n, double* out, void* stream) {
+  if (!out || n < 1) return GSM_E_ARG;
+  double tab[kMathTabDoubles];
+  build_math_tables(tab);
+  double* d_tab = nullptr;
+  if (hipMalloc(&d_tab, sizeof(tab)) != hipSuccess) return GSM_E_HIP;
+  int rc = GSM_OK;
+  if (hipMemcpy(d_tab, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess ||
+      launch_debug_normals(seed, step, stream_id, idx0, n, d_tab, out, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = GSM_E_HIP;
+  hipFree(d_tab);
+  return rc;
+}
+
 extern "C" int gsm_debug_stream_copy(const double* src, double* dst, int64_t n, void* stream) {
   if (!src || !dst || n < 0) return GSM_E_ARG;
   return launch_stream_copy(src, dst, n, (hipStream_t)stream) == hipSuccess ? GSM_OK : GSM_E_HIP;

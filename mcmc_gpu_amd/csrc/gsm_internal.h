@@ -178,6 +178,8 @@ hipError_t launch_pack_static(const StaticFields& S, double2* svx, double2* svy,
 hipError_t launch_residual(const StaticFields& S, int n_chains, const double* beds, double* out, hipStream_t st);
 hipError_t launch_propose(const ProposeArgs& a, hipStream_t st);
 hipError_t launch_propose_scalars(const ProposeArgs& a, hipStream_t st);
+hipError_t launch_debug_normals(uint64_t seed, int64_t step, uint32_t stream_id, uint32_t idx0, int n, const double* mathtab, double* out,
+                                hipStream_t st);
 hipError_t launch_k2_tables(const BlockTable& B, const int32_t* k2_off, double resolution, double* k2tab, hipStream_t st);
 hipError_t launch_spectral_from_noise(const ProposeArgs& a, const int32_t* size_idx, const double* rf_scalars, const double* noise_re,
                                       const double* noise_im, const double* nugget_field, hipStream_t st);

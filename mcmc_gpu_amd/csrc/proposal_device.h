@@ -53,6 +53,19 @@ __device__ __forceinline__ double exp_lean(double x) {
   return ldexp(p, (int)kf);
 }
 
+// sqrt(t) for 0 <= t < 2^500 (here t = -2 log u <= 73.5): v_rsq_f64, one Goldschmidt step and one residual correction (error
+// < 1 ulp) -- the library routine's range scaling, special-case selects and second correction left out.  t = 0 (u = 1,
+// probability 2^-53) is raised to 1e-300: the result 1e-150 stands for 0.
+__device__ __forceinline__ double sqrt_lean(double t) {
+  t = fmax(t, 1e-300);
+  const double y = __builtin_amdgcn_rsq(t);
+  double g = t * y, h = 0.5 * y;
+  const double r = __fma_rn(-h, g, 0.5);
+  g = __fma_rn(g, r, g);
+  h = __fma_rn(h, r, h);
+  return __fma_rn(__fma_rn(-g, g, t), h, g);
+}
+
 // mt: the table of math_tables.h, in LDS
 __device__ __forceinline__ void normals2(uint64_t seed, int64_t step, uint32_t stream, uint32_t idx, double& g1,
                                          double& g2, const double* mt) {
@@ -64,7 +77,7 @@ __device__ __forceinline__ void normals2(uint64_t seed, int64_t step, uint32_t s
   const u32x4 r = philox_draw(((uint64_t)k1 << 32) | k0, step, stream, idx);
   const double u1 = u01_open0_from(r.x, r.y);
   const double u2 = u01_from(r.z, r.w);
-  const double rad = sqrt(-2.0 * log_tab(u1, mt));
+  const double rad = sqrt_lean(-2.0 * log_tab(u1, mt));
   double s, c;
   sincos_tab(u2, mt, s, c);
   g1 = rad * c;

@@ -194,6 +194,24 @@ hipError_t launch_spectral_from_noise(const ProposeArgs& a, const int32_t* size_
   return hipGetLastError();
 }
 
+// test hook (gsm_debug_normals): normals2 exactly as the coefficient phase calls it
+__global__ __launch_bounds__(256) void debug_normals_kernel(uint64_t seed, int64_t step, uint32_t stream_id, uint32_t idx0, int n,
+                                                            const double* __restrict__ mathtab, double* __restrict__ out) {
+  __shared__ double mt[kMathTabDoubles];
+  for (int i = threadIdx.x; i < kMathTabDoubles; i += 256) mt[i] = mathtab[i];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double g1, g2;
+  normals2(seed, step, stream_id, idx0 + (uint32_t)i, g1, g2, mt);
+  out[2 * i] = g1; out[2 * i + 1] = g2;
+}
+hipError_t launch_debug_normals(uint64_t seed, int64_t step, uint32_t stream_id, uint32_t idx0, int n, const double* mathtab, double* out,
+                                hipStream_t st) {
+  hipLaunchKernelGGL(debug_normals_kernel, dim3((n + 255) / 256), dim3(256), 0, st, seed, step, stream_id, idx0, n, mathtab, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_propose(const ProposeArgs& a_in, hipStream_t st) {
   ProposeArgs a = a_in;
   { static int dbg = -1; if (dbg < 0) { const char* v = getenv("GSM_PROPOSE_DBG"); dbg = v ? atoi(v) : 0; } a.dbg = dbg; }
