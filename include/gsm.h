@@ -250,6 +250,15 @@ int gsm_sgs_blocks(gsm_handle h, double* grids, const double* zcond, const int32
  * Replaces: chain_sgs.run's per-iteration loss and guard (MCMC.py:1781-1795). */
 int gsm_sgs_loss(gsm_handle h, const double* beds, const double* trend, double* loss, int32_t* bad, void* stream);
 
+/* The Metropolis decision of one small-scale iteration on the device, so that a batch of iterations needs no host round
+ * trip: loss_next[c] (set to +inf where bad[c] > 0), p = 1 if loss_prev[c] > loss_next[c] else min(1, exp(loss_prev[c] -
+ * loss_next[c])) (a NaN stays a rejection, as with numpy.minimum), accept[c] = u[c] <= p; an accepted chain's loss_prev[c]
+ * becomes loss_next[c].  loss_rec[c * rec_stride] = loss_prev[c] after the decision and acc_rec[c * rec_stride] =
+ * accept[c] (the iteration's column of the caller's [n_chains][rec_stride] record arrays; either may be NULL).  All [dev].
+ * Replaces: chain_sgs.run's acceptance test (MCMC.py:1797-1812). */
+int gsm_sgs_decide(gsm_handle h, const double* loss_next, const int32_t* bad, const double* u, double* loss_prev,
+                   uint8_t* accept, double* loss_rec, uint8_t* acc_rec, int64_t rec_stride, void* stream);
+
 /* Accept / reject bookkeeping of one small-scale iteration: where accept[c] != 0 the block of chain c is copied from
  * `next` into `cur` and resampled counts of the block are incremented (MCMC.py:1803-1812); elsewhere the block of `next`
  * is restored from `cur`.  cur, next [dev, n_chains*H*W], resampled [dev, n_chains*H*W], windows as in gsm_sgs_blocks,

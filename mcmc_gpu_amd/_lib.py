@@ -171,6 +171,7 @@ def load() -> C.CDLL:
     lib.gsm_sgs_blocks.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, dbl, i32, dbl, vp, vp, vp, vp, vp]
     lib.gsm_sgs_loss.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.gsm_sgs_commit.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.gsm_sgs_decide.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.gsm_min_dist_from_mask.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.gsm_debug_stream_copy.argtypes = [vp, vp, i64, vp]
     lib.gsm_debug_normals.argtypes = [C.c_uint64, i64, C.c_uint32, C.c_uint32, i32, vp, vp]

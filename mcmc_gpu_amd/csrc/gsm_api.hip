@@ -808,6 +808,16 @@ extern "C" int gsm_sgs_loss(gsm_handle h, const double* beds, const double* tren
   return GSM_OK;
 }
 
+extern "C" int gsm_sgs_decide(gsm_handle h, const double* loss_next, const int32_t* bad, const double* u, double* loss_prev,
+                              uint8_t* accept, double* loss_rec, uint8_t* acc_rec, int64_t rec_stride, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!loss_next || !bad || !u || !loss_prev || !accept) return fail(h, GSM_E_ARG, "gsm_sgs_decide: NULL pointer");
+  if ((loss_rec || acc_rec) && rec_stride < 1) return fail(h, GSM_E_ARG, "gsm_sgs_decide: rec_stride must be >= 1");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_sgs_decide(h->n_chains, loss_next, bad, u, loss_prev, accept, loss_rec, acc_rec, rec_stride, (hipStream_t)stream));
+  return GSM_OK;
+}
+
 extern "C" int gsm_sgs_commit(gsm_handle h, double* cur, double* next, uint32_t* resampled, const int32_t* windows,
                               const uint8_t* accept, void* stream) {
   if (!h) return GSM_E_ARG;

@@ -158,6 +158,8 @@ struct SgsArgs {
 hipError_t launch_sgs_blocks(const SgsArgs& a, hipStream_t st);
 hipError_t launch_sgs_loss(const StaticFields& S, int n_chains, const double* beds, const double* trend, double* loss, int32_t* bad,
                            hipStream_t st);
+hipError_t launch_sgs_decide(int n_chains, const double* loss_next, const int32_t* bad, const double* u, double* loss_prev,
+                             uint8_t* accept, double* loss_rec, uint8_t* acc_rec, int64_t rec_stride, hipStream_t st);
 hipError_t launch_sgs_commit(int H, int W, int n_chains, double* cur, double* next, uint32_t* resampled, const int32_t* win,
                              const uint8_t* accept, hipStream_t st);
 

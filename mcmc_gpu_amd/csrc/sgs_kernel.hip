@@ -255,6 +255,33 @@ hipError_t launch_sgs_loss(const StaticFields& S, int n_chains, const double* be
   return hipGetLastError();
 }
 
+// the acceptance test of an iteration (gsm.h: gsm_sgs_decide), one thread per chain
+__global__ __launch_bounds__(64) void sgs_decide_kernel(int n, const double* __restrict__ loss_next, const int32_t* __restrict__ bad,
+                                                        const double* __restrict__ u, double* __restrict__ loss_prev,
+                                                        uint8_t* __restrict__ accept, double* loss_rec, uint8_t* acc_rec, int64_t rec_stride) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= n) return;
+  const double ln = (bad[c] > 0) ? INFINITY : loss_next[c];
+  const double lp = loss_prev[c];
+  bool acc = true;
+  if (!(lp > ln)) {
+    const double p = exp(lp - ln);
+    acc = u[c] <= ((p > 1.0) ? 1.0 : p);        // p NaN: the comparison is false (numpy.minimum propagates the NaN)
+  }
+  const double l = acc ? ln : lp;
+  loss_prev[c] = l;
+  accept[c] = acc ? 1 : 0;
+  if (loss_rec) loss_rec[(int64_t)c * rec_stride] = l;
+  if (acc_rec) acc_rec[(int64_t)c * rec_stride] = acc ? 1 : 0;
+}
+
+hipError_t launch_sgs_decide(int n_chains, const double* loss_next, const int32_t* bad, const double* u, double* loss_prev,
+                             uint8_t* accept, double* loss_rec, uint8_t* acc_rec, int64_t rec_stride, hipStream_t st) {
+  hipLaunchKernelGGL(sgs_decide_kernel, dim3((n_chains + 63) / 64), dim3(64), 0, st, n_chains, loss_next, bad, u, loss_prev, accept,
+                     loss_rec, acc_rec, rec_stride);
+  return hipGetLastError();
+}
+
 // accept[c] != 0: the block of chain c goes from `next` to `cur` and its resampled counts are bumped (MCMC.py:1803-1812);
 // else the block of `next` is restored from `cur`, so that next == cur everywhere again.
 __global__ __launch_bounds__(64) void sgs_commit_kernel(int H, int W, double* cur, double* next, uint32_t* resampled, const int32_t* win,

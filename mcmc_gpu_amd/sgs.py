@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import sys
 import time
 from copy import deepcopy
@@ -282,7 +283,54 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
             for c in range(n):
                 sample_values[c, :, 0] = np.asarray(initial_beds[c])[ij[:, 0], ij[:, 1]]
         t0 = time.time()
-        for it in range(n_iter):
+        # Without a normal-score transformer and without per-iteration bed records nothing of an iteration has to come back
+        # to the host before the next one: the draws do not depend on the chain state (chain_sgs.run consumes chain.rng in
+        # the same order whatever is accepted), so a batch of iterations is drawn ahead, uploaded once, and simulated /
+        # scored / decided (gsm_sgs_decide) / committed on the device back to back.
+        batch = int(os.environ.get('GSM_SGS_BATCH', '32')) if (nst is None and not keep_all and not track) else 1
+        it_done = 0
+        while batch > 1 and it_done < n_iter:
+            kb = min(batch, n_iter - it_done)
+            wins = np.empty((kb, n, 4), np.int32); offs = np.zeros((kb, n + 1), np.int32); us = np.empty((kb, n))
+            cells, zs, bases = [], [], np.zeros(kb + 1, np.int64)
+            for c in range(n):                     # per chain in iteration order: each chain owns its generator
+                for j in range(kb):
+                    blk, win, inds, z, us[j, c] = chain._draw_iteration(rngs[c], cond_is_data)
+                    blocks_cache[c, it_done + j] = blk
+                    wins[j, c] = win
+                    cells.append((j, c, inds)); zs.append((j, c, z))
+            cells.sort(key=lambda t: (t[0], t[1])); zs.sort(key=lambda t: (t[0], t[1]))
+            k = 0
+            for j in range(kb):
+                for c in range(n):
+                    offs[j, c + 1] = offs[j, c] + cells[k][2].shape[0]; k += 1
+                bases[j + 1] = bases[j] + offs[j, n]
+            tot = int(bases[kb])
+            d_win = torch.as_tensor(wins).to(dev); d_off = torch.as_tensor(offs).to(dev); d_us = torch.as_tensor(us).to(dev)
+            d_cells = torch.as_tensor(np.ascontiguousarray(np.concatenate([t[2] for t in cells]) if tot else np.zeros((1, 2), np.int32))).to(dev)
+            d_z = torch.as_tensor(np.concatenate([t[2] for t in zs]) if tot else np.zeros(1)).to(dev)
+            d_lrec = torch.empty((n, kb), dtype=torch.float64, device=dev); d_arec = torch.empty((n, kb), dtype=torch.uint8, device=dev)
+            if it_done == 0:
+                d_lprev = f64(loss_prev); d_acc = torch.empty(n, dtype=torch.uint8, device=dev)
+            at = lambda t, off_elems: C.c_void_p(t.data_ptr() + int(off_elems) * t.element_size())
+            with torch.cuda.device(dev):
+                for j in range(kb):
+                    eng._check(lib.gsm_sgs_blocks(h, _ptr(nxt), _ptr(d_zcond), at(d_win, 4 * n * j), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), hw,
+                                                  rad, npts, float(vario["sill"]), at(d_off, (n + 1) * j), at(d_cells, 2 * bases[j]),
+                                                  at(d_z, bases[j]), None, eng._stream()))
+                    eng._check(lib.gsm_sgs_loss(h, _ptr(nxt), _ptr(d_trend), _ptr(d_loss), _ptr(d_bad), eng._stream()))
+                    eng._check(lib.gsm_sgs_decide(h, _ptr(d_loss), _ptr(d_bad), at(d_us, n * j), _ptr(d_lprev), _ptr(d_acc),
+                                                  at(d_lrec, j), at(d_arec, j), kb, eng._stream()))
+                    eng._check(lib.gsm_sgs_commit(h, _ptr(cur), _ptr(nxt), _ptr(resampled), at(d_win, 4 * n * j), _ptr(d_acc), eng._stream()))
+            loss_cache[:, it_done:it_done + kb] = d_lrec.cpu().numpy()
+            step_cache[:, it_done:it_done + kb] = d_arec.cpu().numpy()
+            it_done += kb
+            if progress_bar is not None:
+                el = time.time() - t0
+                print(f"Chain {getattr(chain, 'chain_id', 0)} ({str(getattr(chain, 'seed', 'Unknown'))[:6]}): "
+                      f"{100 * (it_done - 1) / max(n_iter - 1, 1):3.0f}% | it/s: {it_done / max(el, 1e-9):7.2f} | n: {n_iter} | "
+                      f"loss: {loss_cache[0, it_done - 1]:.3e} | acc: {step_cache[0, :it_done].sum() / it_done:.4f}", file=sys.stdout, flush=True)
+        for it in range(it_done, n_iter):
             wins = np.empty((n, 4), np.int32); offs = np.zeros(n + 1, np.int32); us = np.empty(n)
             cells, zs = [], []
             for c in range(n):

@@ -159,3 +159,32 @@ def test_chain_sgs_gpu_equals_oracle_on_more_variograms(vtype, smooth, aniso, np
     blk = ref[6]
     assert ((blk[:, 0] - blk[:, 2] / 2 < 0) | (blk[:, 1] - blk[:, 3] / 2 < 0) | (blk[:, 0] + blk[:, 2] / 2 > H) |
             (blk[:, 1] + blk[:, 3] / 2 > W)).any(), "no block was clipped at the border"
+
+
+def test_batched_iterations_equal_one_by_one(monkeypatch):
+    """run_many_sgs draws a batch of iterations ahead and decides on the device (gsm_sgs_decide); GSM_SGS_BATCH=1 is the
+    iteration-by-iteration path with the decision on the host.  Same chains, same generators: identical results."""
+    from mcmc_gpu_amd import sgs
+    H = 32
+    prob = sc.problem(H)
+    def make():
+        ch = sgs.chain_sgs_gpu(prob["xx"], prob["yy"], prob["bed"], prob["surf"], prob["velx"], prob["vely"], prob["dhdt"], prob["smb"],
+                               prob["cond_bed"], prob["data_mask"], np.ones((H, H), dtype=int), prob["resolution"])
+        ch.set_update_region(True, prob["region_mask"]); ch.set_loss_type(sigma_mc=60.0, massConvInRegion=True)
+        ch.set_normal_transformation(None, do_transform=False); ch.set_trend(None, detrend_map=False)
+        ch.set_variogram("Exponential", 6000.0, float(np.var(prob["bed"])), 0.0, isotropic=True)
+        ch.set_sgs_param(16, 4000.0); ch.set_block_sizes(3, 8, 3, 8)
+        return ch
+    beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(3)]
+    res = []
+    for batch in ("32", "1"):
+        monkeypatch.setenv("GSM_SGS_BATCH", batch)
+        rngs = [np.random.default_rng(900 + i) for i in range(3)]
+        out, rngs = sgs.run_many_sgs(make(), beds, rngs, 75)
+        res.append((out, [r.bit_generator.state for r in rngs]))
+    (a, sa), (b, sb) = res
+    assert sa == sb
+    for x, y in zip(a, b):
+        for k in (0, 3, 4, 5, 6):
+            assert np.array_equal(x[k], y[k]), k
+    assert 0.05 < np.mean([x[4].mean() for x in a]) < 0.95
