@@ -259,6 +259,20 @@ int gsm_sgs_loss(gsm_handle h, const double* beds, const double* trend, double* 
 int gsm_sgs_decide(gsm_handle h, const double* loss_next, const int32_t* bad, const double* u, double* loss_prev,
                    uint8_t* accept, double* loss_rec, uint8_t* acc_rec, int64_t rec_stride, void* stream);
 
+/* scikit-learn's QuantileTransformer(output_distribution="normal") of one feature on the device, as chain_sgs.run applies it
+ * to the whole map around every SGS block (MCMC.py:1766, :1777): out[i] = transform(x[i]) (inverse == 0) or
+ * inverse_transform(x[i]) (inverse != 0), i < n.  quantiles = transformer.quantiles_[:, 0], references =
+ * transformer.references_, both [dev, nq] ascending; x, out [dev, n] (may alias).  NaN stays NaN.  Same arithmetic as
+ * QuantileTransformer._transform_col with scipy.stats.norm.ppf / cdf (Cephes ndtri / ndtr): mcmc_gpu_amd/csrc/normal_score.h. */
+int gsm_qt_transform(gsm_handle h, const double* quantiles, const double* references, int32_t nq, const double* x, double* out,
+                     int64_t n, int32_t inverse, void* stream);
+
+/* gsm_sgs_commit for a chain with a normal-score transformer: the inverse transform touches every cell of the proposed map,
+ * so an accepted chain takes the WHOLE plane of `proposed` (cur[c] = proposed[c]) and the resampled counts of its window are
+ * incremented (MCMC.py:1803-1812); a rejected chain keeps cur.  cur, proposed [dev, n_chains*H*W]. */
+int gsm_sgs_commit_map(gsm_handle h, double* cur, const double* proposed, uint32_t* resampled, const int32_t* windows,
+                       const uint8_t* accept, void* stream);
+
 /* Accept / reject bookkeeping of one small-scale iteration: where accept[c] != 0 the block of chain c is copied from
  * `next` into `cur` and resampled counts of the block are incremented (MCMC.py:1803-1812); elsewhere the block of `next`
  * is restored from `cur`.  cur, next [dev, n_chains*H*W], resampled [dev, n_chains*H*W], windows as in gsm_sgs_blocks,

@@ -1,6 +1,7 @@
 // C ABI of libgsm_hip.so (see include/gsm.h for the contract and the reference interfaces replaced).
 #include "gsm_internal.h"
 #include "math_tables.h"
+#include "normal_score.h"
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -815,6 +816,28 @@ extern "C" int gsm_sgs_decide(gsm_handle h, const double* loss_next, const int32
   if ((loss_rec || acc_rec) && rec_stride < 1) return fail(h, GSM_E_ARG, "gsm_sgs_decide: rec_stride must be >= 1");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, launch_sgs_decide(h->n_chains, loss_next, bad, u, loss_prev, accept, loss_rec, acc_rec, rec_stride, (hipStream_t)stream));
+  return GSM_OK;
+}
+
+extern "C" int gsm_qt_transform(gsm_handle h, const double* quantiles, const double* references, int32_t nq, const double* x,
+                                double* out, int64_t n, int32_t inverse, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!quantiles || !references || !x || !out || nq < 1 || n < 0) return fail(h, GSM_E_ARG, "gsm_qt_transform: bad argument");
+  if (n == 0) return GSM_OK;
+  // sklearn clips the scores at ppf(1e-7 - spacing(1)) and ppf(1 - (1e-7 - spacing(1))) (QuantileTransformer._transform_col)
+  const double lo = 1e-7 - 2.220446049250313e-16;
+  const double clip_min = ns::ndtri(lo), clip_max = ns::ndtri(1.0 - lo);
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_qt(quantiles, references, nq, clip_min, clip_max, x, out, n, inverse, (hipStream_t)stream));
+  return GSM_OK;
+}
+
+extern "C" int gsm_sgs_commit_map(gsm_handle h, double* cur, const double* proposed, uint32_t* resampled, const int32_t* windows,
+                                  const uint8_t* accept, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!cur || !proposed || !resampled || !windows || !accept) return fail(h, GSM_E_ARG, "gsm_sgs_commit_map: NULL pointer");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_sgs_commit_map(h->H, h->W, h->n_chains, cur, proposed, resampled, windows, accept, (hipStream_t)stream));
   return GSM_OK;
 }
 

@@ -160,6 +160,10 @@ hipError_t launch_sgs_loss(const StaticFields& S, int n_chains, const double* be
                            hipStream_t st);
 hipError_t launch_sgs_decide(int n_chains, const double* loss_next, const int32_t* bad, const double* u, double* loss_prev,
                              uint8_t* accept, double* loss_rec, uint8_t* acc_rec, int64_t rec_stride, hipStream_t st);
+hipError_t launch_qt(const double* quantiles, const double* references, int nq, double clip_min, double clip_max, const double* x,
+                     double* out, int64_t n, int inverse, hipStream_t st);
+hipError_t launch_sgs_commit_map(int H, int W, int n_chains, double* cur, const double* proposed, uint32_t* resampled, const int32_t* win,
+                                 const uint8_t* accept, hipStream_t st);
 hipError_t launch_sgs_commit(int H, int W, int n_chains, double* cur, double* next, uint32_t* resampled, const int32_t* win,
                              const uint8_t* accept, hipStream_t st);
 

@@ -27,6 +27,7 @@
 // inside `radius` would make the reference grow the radius by 100 km (MCMC.py:152-156): not built, reported as an error.
 #include "gsm_internal.h"
 #include "residual_device.h"
+#include "normal_score.h"
 #include <math.h>
 
 namespace gsm {
@@ -279,6 +280,45 @@ hipError_t launch_sgs_decide(int n_chains, const double* loss_next, const int32_
                              uint8_t* accept, double* loss_rec, uint8_t* acc_rec, int64_t rec_stride, hipStream_t st) {
   hipLaunchKernelGGL(sgs_decide_kernel, dim3((n_chains + 63) / 64), dim3(64), 0, st, n_chains, loss_next, bad, u, loss_prev, accept,
                      loss_rec, acc_rec, rec_stride);
+  return hipGetLastError();
+}
+
+// normal-score transform, elementwise (gsm.h: gsm_qt_transform); the two tables are staged in LDS when they fit
+constexpr int kQtLds = 4096;
+__global__ __launch_bounds__(256) void qt_kernel(const double* __restrict__ quantiles, const double* __restrict__ references, int nq,
+                                                 double clip_min, double clip_max, const double* x, double* out, int64_t n, int inverse) {
+  __shared__ double tab[2 * kQtLds];
+  const double* q = quantiles;
+  const double* ref = references;
+  if (nq <= kQtLds) {
+    for (int i = threadIdx.x; i < nq; i += 256) { tab[i] = quantiles[i]; tab[kQtLds + i] = references[i]; }
+    __syncthreads();
+    q = tab; ref = tab + kQtLds;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = inverse ? ns::qt_inverse(x[i], q, ref, nq) : ns::qt_forward(x[i], q, ref, nq, clip_min, clip_max);
+}
+hipError_t launch_qt(const double* quantiles, const double* references, int nq, double clip_min, double clip_max, const double* x,
+                     double* out, int64_t n, int inverse, hipStream_t st) {
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(qt_kernel, dim3(blocks), dim3(256), 0, st, quantiles, references, nq, clip_min, clip_max, x, out, n, inverse);
+  return hipGetLastError();
+}
+
+// gsm_sgs_commit_map: an accepted chain takes the whole proposed plane
+__global__ __launch_bounds__(256) void sgs_commit_map_kernel(int H, int W, double* cur, const double* proposed, uint32_t* resampled,
+                                                             const int32_t* win, const uint8_t* accept) {
+  const int chain = blockIdx.x;
+  if (!accept[chain]) return;
+  const size_t base = (size_t)chain * H * W;
+  for (int p = threadIdx.x; p < H * W; p += 256) cur[base + p] = proposed[base + p];
+  const int r0 = win[4 * chain], r1 = win[4 * chain + 1], c0 = win[4 * chain + 2], c1 = win[4 * chain + 3];
+  const int ww = c1 - c0, n = (r1 - r0) * ww;
+  for (int p = threadIdx.x; p < n; p += 256) resampled[base + (size_t)(r0 + p / ww) * W + c0 + p % ww] += 1u;
+}
+hipError_t launch_sgs_commit_map(int H, int W, int n_chains, double* cur, const double* proposed, uint32_t* resampled, const int32_t* win,
+                                 const uint8_t* accept, hipStream_t st) {
+  hipLaunchKernelGGL(sgs_commit_map_kernel, dim3(n_chains), dim3(256), 0, st, H, W, cur, proposed, resampled, win, accept);
   return hipGetLastError();
 }
 

@@ -242,6 +242,13 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
     cond_c = np.asarray(chain.cond_bed, dtype=np.float64) - trend if detrend else np.asarray(chain.cond_bed, dtype=np.float64).copy()
     z_cond = nst.transform(cond_c.reshape(-1, 1)).reshape(H, W) if nst is not None else cond_c
     cond_is_data = ~np.isnan(z_cond)
+    # scikit-learn's QuantileTransformer with normal output and one feature (what the reference's drivers attach,
+    # smallScaleChain_multiprocessing.py:493-496) runs on the device (gsm_qt_transform); any other transformer object is
+    # called on the host once per iteration, where the reference calls it
+    dev_qt = (nst is not None and type(nst).__name__ == 'QuantileTransformer' and getattr(nst, 'output_distribution', None) == 'normal'
+              and getattr(nst, 'quantiles_', None) is not None and nst.quantiles_.ndim == 2 and nst.quantiles_.shape[1] == 1
+              and os.environ.get('GSM_SGS_HOST_TRANSFORM', '0') != '1')
+    host_nst = nst if (nst is not None and not dev_qt) else None
     track = chain.sample_loc is not None
     keep_all = not only_save_last_bed
 
@@ -258,6 +265,11 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
         bed_c = np.stack([np.asarray(b, dtype=np.float64) - trend if detrend else np.asarray(b, dtype=np.float64) for b in initial_beds])
         cur = f64(bed_c)
         nxt = cur.clone()
+        if dev_qt:
+            d_q = f64(nst.quantiles_[:, 0]); d_ref = f64(nst.references_); nq = int(d_q.numel())
+            prop = cur.clone()                                   # proposed beds in data space (inverse transform of nxt)
+        def qt(src, dst, inverse):
+            eng._check(lib.gsm_qt_transform(h, _ptr(d_q), _ptr(d_ref), nq, _ptr(src), _ptr(dst), int(src.numel()), int(inverse), eng._stream()))
         resampled = torch.zeros((n, H, W), dtype=torch.int32, device=dev)
         d_loss = torch.empty(n, dtype=torch.float64, device=dev)
         d_bad = torch.empty(n, dtype=torch.int32, device=dev)
@@ -287,7 +299,7 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
         # to the host before the next one: the draws do not depend on the chain state (chain_sgs.run consumes chain.rng in
         # the same order whatever is accepted), so a batch of iterations is drawn ahead, uploaded once, and simulated /
         # scored / decided (gsm_sgs_decide) / committed on the device back to back.
-        batch = int(os.environ.get('GSM_SGS_BATCH', '32')) if (nst is None and not keep_all and not track) else 1
+        batch = int(os.environ.get('GSM_SGS_BATCH', '32')) if (host_nst is None and not keep_all and not track) else 1
         it_done = 0
         while batch > 1 and it_done < n_iter:
             kb = min(batch, n_iter - it_done)
@@ -315,13 +327,20 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
             at = lambda t, off_elems: C.c_void_p(t.data_ptr() + int(off_elems) * t.element_size())
             with torch.cuda.device(dev):
                 for j in range(kb):
+                    if dev_qt:
+                        qt(cur, nxt, 0)                       # the whole map to normal scores (MCMC.py:1766)
                     eng._check(lib.gsm_sgs_blocks(h, _ptr(nxt), _ptr(d_zcond), at(d_win, 4 * n * j), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), hw,
                                                   rad, npts, float(vario["sill"]), at(d_off, (n + 1) * j), at(d_cells, 2 * bases[j]),
                                                   at(d_z, bases[j]), None, eng._stream()))
-                    eng._check(lib.gsm_sgs_loss(h, _ptr(nxt), _ptr(d_trend), _ptr(d_loss), _ptr(d_bad), eng._stream()))
+                    if dev_qt:
+                        qt(nxt, prop, 1)                      # ... and back (MCMC.py:1777)
+                    eng._check(lib.gsm_sgs_loss(h, _ptr(prop if dev_qt else nxt), _ptr(d_trend), _ptr(d_loss), _ptr(d_bad), eng._stream()))
                     eng._check(lib.gsm_sgs_decide(h, _ptr(d_loss), _ptr(d_bad), at(d_us, n * j), _ptr(d_lprev), _ptr(d_acc),
                                                   at(d_lrec, j), at(d_arec, j), kb, eng._stream()))
-                    eng._check(lib.gsm_sgs_commit(h, _ptr(cur), _ptr(nxt), _ptr(resampled), at(d_win, 4 * n * j), _ptr(d_acc), eng._stream()))
+                    if dev_qt:
+                        eng._check(lib.gsm_sgs_commit_map(h, _ptr(cur), _ptr(prop), _ptr(resampled), at(d_win, 4 * n * j), _ptr(d_acc), eng._stream()))
+                    else:
+                        eng._check(lib.gsm_sgs_commit(h, _ptr(cur), _ptr(nxt), _ptr(resampled), at(d_win, 4 * n * j), _ptr(d_acc), eng._stream()))
             loss_cache[:, it_done:it_done + kb] = d_lrec.cpu().numpy()
             step_cache[:, it_done:it_done + kb] = d_arec.cpu().numpy()
             it_done += kb
@@ -343,13 +362,18 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
             d_off = torch.as_tensor(offs).to(dev)
             d_cells = torch.as_tensor(np.ascontiguousarray(np.concatenate(cells) if offs[-1] else np.zeros((1, 2), np.int32))).to(dev)
             d_z = torch.as_tensor(np.concatenate(zs) if offs[-1] else np.zeros(1)).to(dev)
-            if nst is not None:
+            if dev_qt:
+                qt(cur, nxt, 0)
+            elif host_nst is not None:
                 # the caller's transformer on the whole map, where the reference calls it (MCMC.py:1766)
                 nxt.copy_(f64(np.stack([nst.transform(bed_c[c].reshape(-1, 1)).reshape(H, W) for c in range(n)])))
             with torch.cuda.device(dev):
                 eng._check(lib.gsm_sgs_blocks(h, _ptr(nxt), _ptr(d_zcond), _ptr(d_win), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), hw,
                                               rad, npts, float(vario["sill"]), _ptr(d_off), _ptr(d_cells), _ptr(d_z), None, eng._stream()))
-            if nst is not None:
+            if dev_qt:
+                qt(nxt, prop, 1)
+                loss_next, bad = loss_of(prop)
+            elif host_nst is not None:
                 newsim = nxt.cpu().numpy()
                 bed_next = np.stack([nst.inverse_transform(newsim[c].reshape(-1, 1)).reshape(H, W) for c in range(n)])   # MCMC.py:1777
                 d_next = f64(bed_next)
@@ -361,7 +385,10 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                 p_acc = np.where(loss_prev > loss_next, 1.0, np.minimum(1.0, np.exp(loss_prev - loss_next)))
             acc = us <= p_acc
             d_acc = torch.as_tensor(acc.astype(np.uint8)).to(dev)
-            if nst is not None:
+            if dev_qt:
+                with torch.cuda.device(dev):
+                    eng._check(lib.gsm_sgs_commit_map(h, _ptr(cur), _ptr(prop), _ptr(resampled), _ptr(d_win), _ptr(d_acc), eng._stream()))
+            elif host_nst is not None:
                 for c in np.flatnonzero(acc):
                     bed_c[c] = bed_next[c]
                     r0, r1, c0, c1 = wins[c]
@@ -373,7 +400,7 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
             loss_cache[:, it] = loss_prev
             step_cache[:, it] = acc
             if keep_all or track:
-                if nst is None:
+                if host_nst is None:
                     bed_c = cur.cpu().numpy()
                 if keep_all:
                     bed_cache[:, it] = bed_c + trend if detrend else bed_c
@@ -385,7 +412,7 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                 print(f"Chain {getattr(chain, 'chain_id', 0)} ({str(getattr(chain, 'seed', 'Unknown'))[:6]}): "
                       f"{100 * it / max(n_iter - 1, 1):3.0f}% | it/s: {(it + 1) / max(el, 1e-9):7.2f} | n: {n_iter} | "
                       f"loss: {loss_cache[0, it]:.3e} | acc: {step_cache[0, :it + 1].sum() / (it + 1):.4f}", file=sys.stdout, flush=True)
-        if nst is None:
+        if host_nst is None:
             bed_c = cur.cpu().numpy()
         res = resampled.cpu().numpy().astype(np.float64)
     finally:
