@@ -26,6 +26,7 @@
 // Limits: hw <= 16 (search window 33 x 33), num_points <= 48, window (block) cells <= 1024.  A cell without any neighbour
 // inside `radius` would make the reference grow the radius by 100 km (MCMC.py:152-156): not built, reported as an error.
 #include "gsm_internal.h"
+#include "device_util.h"
 #include "residual_device.h"
 #include "normal_score.h"
 #include <math.h>
@@ -37,16 +38,42 @@ constexpr int kSgsMaxCand = (2 * kSgsMaxHw + 1) * (2 * kSgsMaxHw + 1);   // 1089
 constexpr int kSgsMaxPts = 48;
 constexpr int kSgsStride = kSgsMaxPts + 3;                                // row stride of the augmented matrix
 constexpr int kSgsMaxWin = 1024;
+constexpr int kSgsCandPerLane = (kSgsMaxCand + 63) / 64;                  // 18
 
+// Wave-wide minima on the DPP network (row steps, two row broadcasts, v_readlane of lane 63): a minimum does not depend on
+// the order of its operands, and ds_bpermute shuffles (__shfl_xor) cost an LDS round trip per level -- with 66 minima per
+// simulated cell (neighbour selection, pivot search) they were two thirds of the kernel's time.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_keep_i32(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xF, false); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_keep_f64(double x) {
+  const dev::v2i32 b = __builtin_bit_cast(dev::v2i32, x);
+  dev::v2i32 o;
+  o.x = __builtin_amdgcn_update_dpp(b.x, b.x, CTRL, ROW_MASK, 0xF, false);
+  o.y = __builtin_amdgcn_update_dpp(b.y, b.y, CTRL, ROW_MASK, 0xF, false);
+  return __builtin_bit_cast(double, o);
+}
 __device__ __forceinline__ double wave_min_f64(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
-  return v;
+  v = fmin(v, dpp_keep_f64<0xB1, 0xF>(v));     // quad_perm [1,0,3,2]
+  v = fmin(v, dpp_keep_f64<0x4E, 0xF>(v));     // quad_perm [2,3,0,1]
+  v = fmin(v, dpp_keep_f64<0x141, 0xF>(v));    // row_half_mirror
+  v = fmin(v, dpp_keep_f64<0x140, 0xF>(v));    // row_mirror
+  v = fmin(v, dpp_keep_f64<0x142, 0xA>(v));    // row_bcast:15 into rows 1 and 3
+  v = fmin(v, dpp_keep_f64<0x143, 0xC>(v));    // row_bcast:31 into rows 2 and 3
+  const dev::v2i32 b = __builtin_bit_cast(dev::v2i32, v);
+  dev::v2i32 o;
+  o.x = __builtin_amdgcn_readlane(b.x, 63);
+  o.y = __builtin_amdgcn_readlane(b.y, 63);
+  return __builtin_bit_cast(double, o);
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-  return v;
+  v = min(v, dpp_keep_i32<0xB1, 0xF>(v));
+  v = min(v, dpp_keep_i32<0x4E, 0xF>(v));
+  v = min(v, dpp_keep_i32<0x141, 0xF>(v));
+  v = min(v, dpp_keep_i32<0x140, 0xF>(v));
+  v = min(v, dpp_keep_i32<0x142, 0xA>(v));
+  v = min(v, dpp_keep_i32<0x143, 0xC>(v));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -68,13 +95,28 @@ __device__ __forceinline__ int octant(double dy, double dx) {
   return (ay > ax) ? 1 : 0;                                    // (-3pi/4, -pi/2) | (-pi, -3pi/4]
 }
 
+// One 64-lane workgroup per chain; the block's cells are simulated one after the other.  Everything a cell needs is read
+// from LDS: the part of the grid its search windows can reach (block + hw cells on every side, staged once; simulated values
+// are written into it as the loop goes), the lag covariance table, the candidates' values.  `staged` = 0 (a region beyond
+// kSgsRegionMax cells, or a lag table beyond kSgsLagMax): the same code reads the grid / the table from global memory.
+constexpr int kSgsRegionMax = 6144;                       // doubles: e.g. an 8 x 8 block with hw = 16 needs 40 x 40
+constexpr int kSgsLagMax = (4 * kSgsMaxHw + 1) * (4 * kSgsMaxHw + 1);   // 4225
+struct SgsLds {
+  double* cand_d; double* cand_v; int8_t* cand_s; double* A; double* nb_val; int* nb_i; int* nb_j; double* region; double* lag;
+};
+static size_t sgs_lds_bytes() {
+  return sizeof(double) * (2 * (size_t)kSgsMaxCand + (size_t)(kSgsMaxPts + 1) * kSgsStride + kSgsMaxPts + kSgsRegionMax + kSgsLagMax) +
+         sizeof(int) * 2 * kSgsMaxPts + ((kSgsMaxCand + 7) & ~7);
+}
+
 __global__ __launch_bounds__(64) void sgs_blocks_kernel(const SgsArgs a) {
-  __shared__ double cand_d[kSgsMaxCand];
-  __shared__ int8_t cand_s[kSgsMaxCand];
-  __shared__ double overlay[kSgsMaxWin];
-  __shared__ double A[(kSgsMaxPts + 1) * kSgsStride];
-  __shared__ double nb_val[kSgsMaxPts];
-  __shared__ int nb_i[kSgsMaxPts], nb_j[kSgsMaxPts];
+  extern __shared__ double sgs_lds[];
+  SgsLds L;
+  L.cand_d = sgs_lds; L.cand_v = L.cand_d + kSgsMaxCand; L.A = L.cand_v + kSgsMaxCand;
+  L.nb_val = L.A + (kSgsMaxPts + 1) * kSgsStride; L.region = L.nb_val + kSgsMaxPts; L.lag = L.region + kSgsRegionMax;
+  L.nb_i = (int*)(L.lag + kSgsLagMax); L.nb_j = L.nb_i + kSgsMaxPts; L.cand_s = (int8_t*)(L.nb_j + kSgsMaxPts);
+  double* const cand_d = L.cand_d; double* const cand_v = L.cand_v; int8_t* const cand_s = L.cand_s; double* const A = L.A;
+  double* const nb_val = L.nb_val; int* const nb_i = L.nb_i; int* const nb_j = L.nb_j;
   const int chain = blockIdx.x, lane = threadIdx.x;
   const int H = a.H, W = a.W;
   double* __restrict__ g = a.grid + (size_t)chain * H * W;
@@ -84,44 +126,74 @@ __global__ __launch_bounds__(64) void sgs_blocks_kernel(const SgsArgs a) {
     if (lane == 0) atomicOr(a.err, 1);
     return;
   }
-  // the block's cells: conditioning data (or NaN) now, simulated values as the loop goes; lives in LDS until the end
-  for (int p = lane; p < wh * ww; p += 64) {
-    const int gi = (r0 + p / ww) * W + c0 + p % ww;
-    overlay[p] = a.zcond ? a.zcond[gi] : g[gi];
+  const int hw = a.hw, k8 = a.num_points / 8;
+  const int side = 2 * hw + 1, m = a.m, lag_side = 2 * m + 1;
+  const uint32_t side_magic = 65536u / (uint32_t)side + 1u;      // p / side for p < 1985 (side <= 33) as a multiply
+  // region of the grid the search windows of the block's cells can reach
+  const int ri0 = max(0, r0 - hw), ri1 = min(H, r1 + hw), rj0 = max(0, c0 - hw), rj1 = min(W, c1 + hw);
+  const int rh = ri1 - ri0, rw = rj1 - rj0;
+  const bool staged = rh * rw <= kSgsRegionMax;
+  // block cells: conditioning data (or NaN) now, simulated values as the loop goes; in LDS until the end
+  double* const overlay = staged ? L.region : L.region;         // unstaged: the first wh * ww doubles hold the block only
+  if (staged) {
+    for (int p = lane; p < rh * rw; p += 64) {
+      const int i = ri0 + p / rw, j = rj0 + p % rw;
+      const int gi = i * W + j;
+      const bool in_block = i >= r0 && i < r1 && j >= c0 && j < c1;
+      L.region[p] = (in_block && a.zcond) ? a.zcond[gi] : g[gi];
+    }
+  } else {
+    for (int p = lane; p < wh * ww; p += 64) {
+      const int gi = (r0 + p / ww) * W + c0 + p % ww;
+      overlay[p] = a.zcond ? a.zcond[gi] : g[gi];
+    }
   }
+  const bool lag_lds = lag_side * lag_side <= kSgsLagMax;
+  if (lag_lds) for (int p = lane; p < lag_side * lag_side; p += 64) L.lag[p] = a.lag[p];
+  const double* __restrict__ lag = lag_lds ? L.lag : a.lag;
   __syncthreads();
+  auto block_index = [&](int i, int j) { return staged ? (i - ri0) * rw + (j - rj0) : (i - r0) * ww + (j - c0); };
   auto value_at = [&](int i, int j) -> double {
+    if (staged) return L.region[(i - ri0) * rw + (j - rj0)];
     if (i >= r0 && i < r1 && j >= c0 && j < c1) return overlay[(i - r0) * ww + (j - c0)];
     return g[i * W + j];
   };
-  const int hw = a.hw, k8 = a.num_points / 8;
-  const int side = 2 * hw + 1, m = a.m, lag_side = 2 * m + 1;
-  auto lag_cov = [&](int di, int dj) { return a.lag[(di + m) * lag_side + dj + m]; };
+  auto lag_cov = [&](int di, int dj) { return lag[(di + m) * lag_side + dj + m]; };
   const int k_lo = a.cell_off[chain], k_hi = a.cell_off[chain + 1];
   for (int k = k_lo; k < k_hi; ++k) {
     const int i0 = a.cells[2 * k], j0 = a.cells[2 * k + 1];
     if (i0 < r0 || i0 >= r1 || j0 < c0 || j0 >= c1) { if (lane == 0) atomicOr(a.err, 2); continue; }
-    const int op = (i0 - r0) * ww + (j0 - c0);
+    const int op = block_index(i0, j0);
     if (!isnan(overlay[op])) {                       // conditioned already: nothing drawn for it (MCMC.py:141)
       if (a.trace && lane == 0) { a.trace[3 * k] = -1.0; a.trace[3 * k + 1] = overlay[op]; a.trace[3 * k + 2] = 0.0; }
       continue;
     }
-    // ---- 1 candidates of the search window -> (distance, sector) ------------------------------------
+    // ---- 1 candidates of the search window -> (distance, sector) in registers, value in LDS -----------
+    // candidate p = lane + 64 t of the (2 hw + 1)^2 window, t < kSgsCandPerLane: the loops over t are unrolled, so the
+    // two arrays live in registers and the 2 * num_points selection rounds below never touch LDS
     const double x0 = a.xs[j0], y0 = a.ys[i0];
-    for (int p = lane; p < side * side; p += 64) {
-      const int i = i0 - hw + p / side, j = j0 - hw + p % side;
+    double cd[kSgsCandPerLane];
+    int cs[kSgsCandPerLane];
+#pragma unroll
+    for (int t = 0; t < kSgsCandPerLane; ++t) {
+      const int p = lane + 64 * t;
       int sec = -1;
       double d = 0.0;
-      if (i >= 0 && i < H && j >= 0 && j < W) {
-        const double v = value_at(i, j);
-        if (!isnan(v)) {
-          const double dx = x0 - a.xs[j], dy = y0 - a.ys[i];
-          d = sqrt(dx * dx + dy * dy);
-          if (d < a.radius) sec = octant(dy, dx);
+      if (p < side * side) {
+        const int io = (int)(((uint32_t)p * side_magic) >> 16);
+        const int i = i0 - hw + io, j = j0 - hw + (p - io * side);
+        double v = 0.0;
+        if (i >= 0 && i < H && j >= 0 && j < W) {
+          v = value_at(i, j);
+          if (!isnan(v)) {
+            const double dx = x0 - a.xs[j], dy = y0 - a.ys[i];
+            d = sqrt(dx * dx + dy * dy);
+            if (d < a.radius) sec = octant(dy, dx);
+          }
         }
+        cand_v[p] = v;
       }
-      cand_d[p] = d;
-      cand_s[p] = (int8_t)sec;
+      cd[t] = d; cs[t] = sec;
     }
     __syncthreads();
     // per sector, in ascending (distance, window position): extract up to k8 points
@@ -132,18 +204,20 @@ __global__ __launch_bounds__(64) void sgs_blocks_kernel(const SgsArgs a) {
       for (int r = 0; r < k8; ++r) {
         double best_d = INFINITY;
         int best_p = 0x7fffffff;
-        for (int p = lane; p < side * side; p += 64) {
-          if (cand_s[p] != s) continue;
-          const double d = cand_d[p];
-          if (d < prev_d || (d == prev_d && p <= prev_p)) continue;        // taken in an earlier round
-          if (d < best_d || (d == best_d && p < best_p)) { best_d = d; best_p = p; }
+#pragma unroll
+        for (int t = 0; t < kSgsCandPerLane; ++t) {
+          if (64 * t >= side * side) break;                    // wave-uniform: no candidate in this slot for any lane
+          const int p = lane + 64 * t;
+          const double d = cd[t];
+          const bool open = (cs[t] == s) && !(d < prev_d || (d == prev_d && p <= prev_p));    // not taken in an earlier round
+          if (open && (d < best_d || (d == best_d && p < best_p))) { best_d = d; best_p = p; }
         }
         const double wd = wave_min_f64(best_d);
         if (wd == INFINITY) break;                                          // sector exhausted
         const int wp = wave_min_i32((best_d == wd) ? best_p : 0x7fffffff);
         if (lane == 0) {
-          const int i = i0 - hw + wp / side, j = j0 - hw + wp % side;
-          nb_i[n] = i; nb_j[n] = j; nb_val[n] = value_at(i, j);
+          const int io = (int)(((uint32_t)wp * side_magic) >> 16);
+          nb_i[n] = i0 - hw + io; nb_j[n] = j0 - hw + (wp - io * side); nb_val[n] = cand_v[wp];
         }
         prev_d = wd; prev_p = wp;
         ++n;
@@ -178,11 +252,16 @@ __global__ __launch_bounds__(64) void sgs_blocks_kernel(const SgsArgs a) {
         A[piv * kSgsStride + lane] = t;
       }
       __syncthreads();
-      if (lane < N && lane != kk) {
-        const double f = A[lane * kSgsStride + kk] / A[kk * kSgsStride + kk];
-        for (int c = kk + 1; c <= N; ++c) A[lane * kSgsStride + c] -= f * A[kk * kSgsStride + c];
-        A[lane * kSgsStride + kk] = 0.0;
+      // row update: lane = (row slot, column slot) of a 16 x 4 arrangement; a lane takes every fourth column of its rows --
+      // the same a - f * b per entry, f = A[row][kk] / pivot, as a row-at-a-time loop
+      const double pv = A[kk * kSgsStride + kk];
+      for (int row = lane >> 2; row < N; row += 16) {
+        if (row == kk) continue;
+        const double f = A[row * kSgsStride + kk] / pv;
+        for (int c = kk + 1 + (lane & 3); c <= N; c += 4) A[row * kSgsStride + c] -= f * A[kk * kSgsStride + c];
       }
+      __syncthreads();
+      if (lane < N && lane != kk) A[lane * kSgsStride + kk] = 0.0;
       __syncthreads();
     }
     if (singular) {
@@ -202,12 +281,21 @@ __global__ __launch_bounds__(64) void sgs_blocks_kernel(const SgsArgs a) {
     }
     __syncthreads();
   }
-  for (int p = lane; p < wh * ww; p += 64) g[(r0 + p / ww) * W + c0 + p % ww] = overlay[p];
+  for (int p = lane; p < wh * ww; p += 64) {
+    const int i = r0 + p / ww, j = c0 + p % ww;
+    g[i * W + j] = overlay[block_index(i, j)];
+  }
 }
 
 hipError_t launch_sgs_blocks(const SgsArgs& a, hipStream_t st) {
   if (a.hw < 1 || a.hw > kSgsMaxHw || a.num_points < 8 || a.num_points > kSgsMaxPts) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(sgs_blocks_kernel, dim3(a.n_chains), dim3(64), 0, st, a);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)sgs_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sgs_blocks_kernel, dim3(a.n_chains), dim3(64), sgs_lds_bytes(), st, a);
   return hipGetLastError();
 }
 
