@@ -75,11 +75,7 @@ __device__ __forceinline__ int wave_min_i32(int v) {
   v = min(v, dpp_keep_i32<0x143, 0xC>(v));
   return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+__device__ __forceinline__ double wave_sum_f64(double v) { return dev::wave64_sum(v); }     // DPP tree, wave-uniform result
 
 // sector b + 4 in 0..7 of atan2(dy, dx) in (b pi/4, (b+1) pi/4]
 __device__ __forceinline__ int octant(double dy, double dx) {
