@@ -22,7 +22,8 @@ Prints ONE JSON line on rank 0 (see the driver contract): metric chain-steps/s, 
   cpu_baseline  -- the NumPy oracle (bit-validated restatement of the reference's CPU loop) under the reference's
                    multiprocessing.Pool pattern on this host's cores, bounded sample, rank 0 at N=1 only
   other_configs -- (N=1, default workload only) short measurements of BASELINE configs[3] (512x512, precomputed-Cholesky
-                   generator, MFMA roofline) and of one GPU's shard of configs[4] (1024x1024, fp32 state) in the same run.
+                   generator, MFMA roofline), of one GPU's shard of configs[4] (1024x1024, fp32 state) and of configs[0] (the
+                   small-scale chain, 64x64 grid x 4 chains) on the device, in the same run.
 """
 import argparse
 import json
@@ -297,6 +298,42 @@ def measure(args, H, n_local, generator, state, inner, batch, steps, warmup, ran
     }
 
 
+def measure_small_scale(H=64, n_chains=4, n_iter=400, cpu_iters=40):
+    """BASELINE configs[0] (smallScaleChain 64x64 grid, 4 chains -- the reference's CPU-runnable case) through the product's
+    small-scale chain on the device: SGS-block Metropolis iterations per second, all chains in one handle."""
+    import numpy as np
+    from mcmc_gpu_amd import sgs, synthetic
+    prob, ch = synthetic.sgs_template(H, transform=True)
+    beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(n_chains)]
+    sgs.run_many_sgs(ch, beds[:1], [np.random.default_rng(1)], 20)           # warm-up
+    rngs = [np.random.default_rng(900 + i) for i in range(n_chains)]
+    t0 = time.perf_counter()
+    out, _ = sgs.run_many_sgs(ch, beds, rngs, n_iter)
+    dt = time.perf_counter() - t0
+    cpu = None
+    if cpu_iters > 0:          # the oracle's restatement of chain_sgs.run (MCMC.py:1599-1911), one chain on one host core
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle"))
+        import sgs_oracle as so
+        v = ch._vario()
+        cfg = so.SgsConfig(prob["xx"], prob["yy"], prob["surf"], prob["velx"], prob["vely"], prob["dhdt"], prob["smb"], prob["cond_bed"],
+                           prob["data_mask"], np.ones((H, H), dtype=int), prob["region_mask"], prob["resolution"], 60.0,
+                           [0, 0.0, 6000.0, 6000.0, float(v["sill"]), "Exponential", None], [16, 4000.0, False, 0], 3, 8, 3, 8,
+                           trend=ch.trend if ch.detrend_map else None, nst_trans=ch.nst_trans if ch.do_transform else None)
+        t1 = time.perf_counter()
+        ref = so.run_chain_sgs(cfg, beds[0], cpu_iters, np.random.default_rng(900))
+        cpu = {"value": cpu_iters / (time.perf_counter() - t1), "unit": "chain-iterations/s", "cores": 1, "kind": "port",
+               "sample": f"1 chain x {cpu_iters} iterations, NumPy oracle of MCMC.py:1599-1911",
+               "first_iterations_equal_device": bool(np.array_equal(ref[4], out[0][4][:cpu_iters]))}
+    return {"cpu_baseline": cpu,
+            "metric": f"chain-iterations/sec of the small-scale (SGS block) chain on a {H}x{H} grid x {n_chains} chains",
+            "value": n_chains * n_iter / dt, "unit": "chain-iterations/s", "n_gpus": 1, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"smallScaleChain {H}x{H} grid, {n_chains} chains, exponential variogram, 16 neighbours, blocks 3-8, "
+                                   f"QuantileTransformer(1000) normal-score transform {'on the device' if ch.do_transform else 'absent (scikit-learn not importable)'} "
+                                   "(BASELINE configs[0], here on the GPU; host draws with the reference's NumPy generator calls)",
+                       "iterations": n_iter},
+            "accept_rate": float(np.mean([o[4].mean() for o in out])), "timed_seconds": dt}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -375,6 +412,12 @@ def main():
             except Exception as e:      # the headline line must not be lost to a failure here; the failure is reported
                 extras[name] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        try:
+            extras["configs[0] on the device"] = measure_small_scale(cpu_iters=0 if args.no_cpu_baseline else 40)
+            extras["configs[0] on the device"]["wall_seconds_incl_setup"] = time.perf_counter() - t0
+        except Exception as e:
+            extras["configs[0] on the device"] = {"error": f"{type(e).__name__}: {e}"}
         out["other_configs"] = extras
     if rank == 0:
         print(json.dumps(out))

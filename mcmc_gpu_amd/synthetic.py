@@ -61,3 +61,41 @@ def template(H, W=None, sigma_mc=5.0, block_range=None, model="Matern", smoothne
         ch.set_crf_data_weight(rf)
         ch.set_update_type('CRF_weight')
     return prob, ch, rf
+
+
+def sgs_template(H, transform=True):
+    """Small-scale chain (chain_sgs_gpu) on the synthetic problem, configured like the reference's small-scale driver
+    (smallScaleChain_multiprocessing.py:470-560): conditioning data along flight-line-like rows / columns, exponential
+    variogram, 16 neighbours, blocks of 3-8 cells, optionally scikit-learn's QuantileTransformer as normal-score transform.
+    Returns (problem dict, chain)."""
+    from . import sgs
+    prob = synthetic_problem(H)
+    data_mask = np.zeros((H, H), dtype=bool)
+    data_mask[::4, :] = True
+    data_mask[:, ::8] = True
+    cond = np.where(data_mask, prob["bed"], np.nan)
+    region = np.zeros((H, H), dtype=int)
+    region[H // 8: 7 * H // 8, H // 8: 7 * H // 8] = 1
+    prob.update(data_mask=data_mask, cond_bed=cond, region_mask=region)
+    ch = sgs.chain_sgs_gpu(prob["xx"], prob["yy"], prob["bed"], prob["surf"], prob["velx"], prob["vely"], prob["dhdt"], prob["smb"],
+                           cond, data_mask, np.ones((H, H), dtype=int), prob["resolution"])
+    ch.set_update_region(True, region)
+    ch.set_loss_type(sigma_mc=60.0, massConvInRegion=True)
+    nst, trend = None, None
+    if transform:
+        try:                        # as the driver does (:485-493): smooth trend, transformer fitted on all of (bed - trend)
+            from scipy.ndimage import gaussian_filter
+            from sklearn.preprocessing import QuantileTransformer
+            trend = gaussian_filter(prob["bed"], sigma=10)
+            nst = QuantileTransformer(n_quantiles=1000, output_distribution="normal", random_state=0,
+                                      subsample=None).fit((prob["bed"] - trend).reshape(-1, 1))
+        except ImportError:
+            nst, trend = None, None
+    ch.set_normal_transformation(nst, do_transform=nst is not None)
+    ch.set_trend(trend, detrend_map=trend is not None)
+    sill = 1.0 if nst is not None else float(np.var(prob["bed"]))      # normal scores have unit variance
+    ch.set_variogram("Exponential", 6000.0, sill, 0.0, isotropic=True)
+    ch.set_sgs_param(16, 4000.0)
+    ch.set_block_sizes(3, 8, 3, 8)
+    return prob, ch
+
