@@ -57,9 +57,23 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile the HIP sources for gfx950 into mcmc_gpu_amd/libgsm_hip.so (in-tree)."""
+    """Compile the HIP sources for gfx950 into mcmc_gpu_amd/libgsm_hip.so (in-tree).  Ranks of one node that start together
+    (bench.py --gpus N, largeScaleChain_mp) take a file lock: one of them builds, the others find the library current."""
     if not force and not _stale():
         return LIB_PATH
+    import fcntl
+    OBJ_DIR.mkdir(exist_ok=True)
+    with open(OBJ_DIR / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():          # another process built it while this one waited
+                return LIB_PATH
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> Path:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libgsm_hip.so")
