@@ -244,6 +244,32 @@ int gsm_sgs_blocks(gsm_handle h, double* grids, const double* zcond, const int32
                    const double* y_axis, const double* lag_cov, int32_t hw, double radius, int32_t num_points, double sill,
                    const int32_t* cell_off, const int32_t* cells, const double* z, double* trace, void* stream);
 
+/* gsm_sgs_blocks for batches of iterations: no trace, the chain's cells are cells[cell_off[c] .. cell_off[c] + cell_cnt[c])
+ * when cell_cnt is given (else .. cell_off[c + 1]), and NO synchronisation: device-side errors accumulate in the handle and
+ * are reported by gsm_sgs_check. */
+int gsm_sgs_blocks_batch(gsm_handle h, double* grids, const double* zcond, const int32_t* windows, const double* x_axis,
+                         const double* y_axis, const double* lag_cov, int32_t hw, double radius, int32_t num_points, double sill,
+                         const int32_t* cell_off, const int32_t* cell_cnt, const int32_t* cells, const double* z, void* stream);
+/* Synchronises the stream and reports what gsm_sgs_blocks_batch calls since the last check have flagged (GSM_OK if nothing). */
+int gsm_sgs_check(gsm_handle h, void* stream);
+
+/* Philox mode of the small-scale chain: the draws of n_iters iterations of every chain on the device -- what chain_sgs.run takes
+ * from chain.rng per iteration (MCMC.py:1750-1765 block centre with rejection on region_mask and block sizes, :128 the visiting
+ * order, :165 one normal per simulated cell, :1797 the accept uniform), from Philox4x32-10 counters (draw index, stream 4,
+ * iteration), key = seeds[c]:
+ *   draws 0..63: centre attempts (row = mulhi(x, H), col = mulhi(y, W)), the first with region_mask == 1 (any if NULL) is taken;
+ *   draw 64: block sizes bs_x = min_x + mulhi(x, max_x - min_x), bs_y likewise (numpy's integers(low, high): high excluded), accept
+ *   uniform from (z, w); draws 128 + p: visiting key of window cell p (row-major) -- cells are visited in ascending (key, p);
+ *   draws 2048 + p / 2: the standard normal of cell p (first / second Box-Muller value for even / odd p).
+ * Outputs, [dev], record r = j * n_chains + c for iteration iter0 + j: windows[4 r] (r0, r1, c0, c1 as MCMC.py:1758-1761),
+ * blocks[4 r] (row, col, bs_x, bs_y), cell_cnt[r], cell_off[r] = r * max_cells, cells[2 (r max_cells + k)] the k-th visited cell,
+ * z[r max_cells + k] its normal (0 for a conditioning cell: is_data != 0), u[r].  max_cells >= (max_x - 1) * (max_y - 1) windows fit.
+ * oracle/sgs_philox_oracle.py restates it. */
+int gsm_sgs_draw_philox(gsm_handle h, const uint64_t* seeds, int64_t iter0, int32_t n_iters, const uint8_t* region_mask,
+                        const uint8_t* is_data, int32_t min_x, int32_t max_x, int32_t min_y, int32_t max_y, int32_t max_cells,
+                        int32_t* windows, int32_t* blocks, int32_t* cell_off, int32_t* cell_cnt, int32_t* cells, double* z, double* u,
+                        void* stream);
+
 /* Loss and thickness guard of proposed beds over the whole grid: loss[c] = nansum(residual(bed_c + trend)^2 where
  * mc_mask == 1) / (2 sigma^2), bad[c] = number of cells with update_mask == 1 (set it to grounded_ice_mask) and
  * surf - (bed_c + trend) <= 0.  beds [dev, n_chains*H*W], trend [dev, H*W] or NULL, loss [dev, n_chains], bad [dev, n_chains].

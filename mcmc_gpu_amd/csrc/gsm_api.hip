@@ -768,34 +768,91 @@ extern "C" int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* co
   return GSM_OK;
 }
 
+static int sgs_fill(gsm_handle h, SgsArgs& a, double* grids, const double* zcond, const int32_t* windows, const double* x_axis,
+                    const double* y_axis, const double* lag_cov, int32_t hw, double radius, int32_t num_points, double sill,
+                    const int32_t* cell_off, const int32_t* cells, const double* z, const char* who) {
+  if (!grids || !windows || !x_axis || !y_axis || !lag_cov || !cell_off || !cells || !z) return fail(h, GSM_E_ARG, std::string(who) + ": NULL pointer");
+  if (hw < 1 || hw > 16) return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": search half-width (radius / grid spacing) must be in [1, 16] cells");
+  if (num_points < 8 || num_points > 48) return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": num_points must be in [8, 48]");
+  if (!(radius > 0.0)) return fail(h, GSM_E_ARG, std::string(who) + ": radius must be > 0");
+  a.H = h->H; a.W = h->W; a.n_chains = h->n_chains;
+  a.grid = grids; a.zcond = zcond; a.win = windows; a.xs = x_axis; a.ys = y_axis; a.lag = lag_cov;
+  a.hw = hw; a.m = 2 * hw; a.num_points = num_points; a.radius = radius; a.sill = sill;
+  a.cell_off = cell_off; a.cells = cells; a.z = z; a.err = h->d_err;
+  return GSM_OK;
+}
+
+static int sgs_report(gsm_handle h, hipStream_t st, const char* who) {
+  int32_t flag = 0;
+  HIPCHK(h, hipMemcpyAsync(&flag, h->d_err, sizeof(flag), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (!flag) return GSM_OK;
+  hipMemsetAsync(h->d_err, 0, sizeof(int32_t), st);
+  hipStreamSynchronize(st);
+  const std::string w(who);
+  if (flag & 4) return fail(h, GSM_E_UNSUPPORTED, w + ": a cell has no conditioning value within the search radius (the reference's "
+                                                   "radius-widening fallback, MCMC.py:152-156, is not built)");
+  if (flag & 8) return fail(h, GSM_E_DEVICE_DATA, w + ": singular kriging system");
+  if (flag & 16) return fail(h, GSM_E_DEVICE_DATA, w + ": no block centre inside the region mask after 64 attempts");
+  return fail(h, GSM_E_DEVICE_DATA, w + ": window outside the grid / larger than 1024 cells (or than max_cells), or a listed cell outside its window");
+}
+
 extern "C" int gsm_sgs_blocks(gsm_handle h, double* grids, const double* zcond, const int32_t* windows, const double* x_axis,
                               const double* y_axis, const double* lag_cov, int32_t hw, double radius, int32_t num_points, double sill,
                               const int32_t* cell_off, const int32_t* cells, const double* z, double* trace, void* stream) {
   if (!h) return GSM_E_ARG;
-  if (!grids || !windows || !x_axis || !y_axis || !lag_cov || !cell_off || !cells || !z)
-    return fail(h, GSM_E_ARG, "gsm_sgs_blocks: NULL pointer");
-  if (hw < 1 || hw > 16) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_blocks: search half-width (radius / grid spacing) must be in [1, 16] cells");
-  if (num_points < 8 || num_points > 48) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_blocks: num_points must be in [8, 48]");
-  if (!(radius > 0.0)) return fail(h, GSM_E_ARG, "gsm_sgs_blocks: radius must be > 0");
+  SgsArgs a{};
+  int rc = sgs_fill(h, a, grids, zcond, windows, x_axis, y_axis, lag_cov, hw, radius, num_points, sill, cell_off, cells, z, "gsm_sgs_blocks");
+  if (rc) return rc;
+  a.cell_cnt = nullptr; a.trace = trace;
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(h, hipSetDevice(h->device));
-  SgsArgs a{};
-  a.H = h->H; a.W = h->W; a.n_chains = h->n_chains;
-  a.grid = grids; a.zcond = zcond; a.win = windows; a.xs = x_axis; a.ys = y_axis; a.lag = lag_cov;
-  a.hw = hw; a.m = 2 * hw; a.num_points = num_points; a.radius = radius; a.sill = sill;
-  a.cell_off = cell_off; a.cells = cells; a.z = z; a.trace = trace; a.err = h->d_err;
   HIPCHK(h, launch_sgs_blocks(a, st));
-  int32_t flag = 0;
-  HIPCHK(h, hipMemcpyAsync(&flag, h->d_err, sizeof(flag), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  if (flag) {
-    hipMemsetAsync(h->d_err, 0, sizeof(int32_t), st);
-    hipStreamSynchronize(st);
-    if (flag & 4) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_blocks: a cell has no conditioning value within the search radius (the reference's "
-                                                     "radius-widening fallback, MCMC.py:152-156, is not built)");
-    if (flag & 8) return fail(h, GSM_E_DEVICE_DATA, "gsm_sgs_blocks: singular kriging system");
-    return fail(h, GSM_E_DEVICE_DATA, "gsm_sgs_blocks: window outside the grid / larger than 1024 cells, or a listed cell outside its window");
+  return sgs_report(h, st, "gsm_sgs_blocks");
+}
+
+extern "C" int gsm_sgs_blocks_batch(gsm_handle h, double* grids, const double* zcond, const int32_t* windows, const double* x_axis,
+                                    const double* y_axis, const double* lag_cov, int32_t hw, double radius, int32_t num_points, double sill,
+                                    const int32_t* cell_off, const int32_t* cell_cnt, const int32_t* cells, const double* z, void* stream) {
+  if (!h) return GSM_E_ARG;
+  SgsArgs a{};
+  int rc = sgs_fill(h, a, grids, zcond, windows, x_axis, y_axis, lag_cov, hw, radius, num_points, sill, cell_off, cells, z, "gsm_sgs_blocks_batch");
+  if (rc) return rc;
+  a.cell_cnt = cell_cnt; a.trace = nullptr;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_sgs_blocks(a, (hipStream_t)stream));
+  return GSM_OK;
+}
+
+extern "C" int gsm_sgs_check(gsm_handle h, void* stream) {
+  if (!h) return GSM_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  return sgs_report(h, (hipStream_t)stream, "gsm_sgs_check");
+}
+
+extern "C" int gsm_sgs_draw_philox(gsm_handle h, const uint64_t* seeds, int64_t iter0, int32_t n_iters, const uint8_t* region_mask,
+                                   const uint8_t* is_data, int32_t min_x, int32_t max_x, int32_t min_y, int32_t max_y, int32_t max_cells,
+                                   int32_t* windows, int32_t* blocks, int32_t* cell_off, int32_t* cell_cnt, int32_t* cells, double* z,
+                                   double* u, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!seeds || !is_data || !windows || !blocks || !cell_off || !cell_cnt || !cells || !z || !u)
+    return fail(h, GSM_E_ARG, "gsm_sgs_draw_philox: NULL pointer");
+  if (n_iters < 1 || n_iters > 65535 || iter0 < 0) return fail(h, GSM_E_ARG, "gsm_sgs_draw_philox: n_iters must be in [1, 65535], iter0 >= 0");
+  if (min_x < 1 || max_x <= min_x || min_y < 1 || max_y <= min_y) return fail(h, GSM_E_ARG, "gsm_sgs_draw_philox: block size ranges must be 1 <= min < max");
+  if (max_cells < (max_x - 1) * (max_y - 1) || max_cells > 1024) return fail(h, GSM_E_ARG, "gsm_sgs_draw_philox: max_cells must hold the largest block and be <= 1024");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->d_mathtab) {
+    double tab[kMathTabDoubles];
+    build_math_tables(tab);
+    HIPCHK(h, hipMalloc(&h->d_mathtab, sizeof(tab)));
+    HIPCHK(h, hipMemcpy(h->d_mathtab, tab, sizeof(tab), hipMemcpyHostToDevice));
   }
+  SgsDrawArgs a{};
+  a.H = h->H; a.W = h->W; a.n_chains = h->n_chains; a.n_iters = n_iters; a.iter0 = iter0; a.seeds = seeds;
+  a.region_mask = region_mask; a.is_data = is_data; a.min_x = min_x; a.max_x = max_x; a.min_y = min_y; a.max_y = max_y;
+  a.max_cells = max_cells; a.mathtab = h->d_mathtab;
+  a.win = windows; a.blk = blocks; a.cell_off = cell_off; a.cell_cnt = cell_cnt; a.cells = cells; a.z = z; a.u = u; a.err = h->d_err;
+  HIPCHK(h, launch_sgs_draw(a, (hipStream_t)stream));
   return GSM_OK;
 }
 

@@ -149,13 +149,26 @@ struct SgsArgs {
   const double* lag;       // [(2m+1)^2] covariance at integer lag (di, dj), m = 2 * hw
   int hw, m, num_points;
   double radius, sill;
-  const int32_t* cell_off; // [n_chains+1]
+  const int32_t* cell_off; // [n_chains+1] (or [n_chains] with cell_cnt)
+  const int32_t* cell_cnt; // optional [n_chains]: number of cells of each chain
   const int32_t* cells;    // [total*2] (i, j) in simulation order
   const double* z;         // [total] standard normals
   double* trace;           // optional [total*3]: (neighbours, estimate, variance)
   int32_t* err;
 };
 hipError_t launch_sgs_blocks(const SgsArgs& a, hipStream_t st);
+struct SgsDrawArgs {
+  int H, W, n_chains, n_iters;
+  int64_t iter0;
+  const uint64_t* seeds;
+  const uint8_t* region_mask;   // nullable
+  const uint8_t* is_data;
+  int min_x, max_x, min_y, max_y, max_cells;
+  const double* mathtab;
+  int32_t* win; int32_t* blk; int32_t* cell_off; int32_t* cell_cnt; int32_t* cells; double* z; double* u;
+  int32_t* err;
+};
+hipError_t launch_sgs_draw(const SgsDrawArgs& a, hipStream_t st);
 hipError_t launch_sgs_loss(const StaticFields& S, int n_chains, const double* beds, const double* trend, double* loss, int32_t* bad,
                            hipStream_t st);
 hipError_t launch_sgs_decide(int n_chains, const double* loss_next, const int32_t* bad, const double* u, double* loss_prev,

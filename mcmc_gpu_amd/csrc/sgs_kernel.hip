@@ -29,6 +29,7 @@
 #include "device_util.h"
 #include "residual_device.h"
 #include "normal_score.h"
+#include "proposal_device.h"
 #include <math.h>
 
 namespace gsm {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(64) void sgs_blocks_kernel(const SgsArgs a) {
     return g[i * W + j];
   };
   auto lag_cov = [&](int di, int dj) { return lag[(di + m) * lag_side + dj + m]; };
-  const int k_lo = a.cell_off[chain], k_hi = a.cell_off[chain + 1];
+  const int k_lo = a.cell_off[chain], k_hi = a.cell_cnt ? k_lo + a.cell_cnt[chain] : a.cell_off[chain + 1];
   for (int k = k_lo; k < k_hi; ++k) {
     const int i0 = a.cells[2 * k], j0 = a.cells[2 * k + 1];
     if (i0 < r0 || i0 >= r1 || j0 < c0 || j0 >= c1) { if (lane == 0) atomicOr(a.err, 2); continue; }
@@ -364,6 +365,59 @@ hipError_t launch_sgs_decide(int n_chains, const double* loss_next, const int32_
                              uint8_t* accept, double* loss_rec, uint8_t* acc_rec, int64_t rec_stride, hipStream_t st) {
   hipLaunchKernelGGL(sgs_decide_kernel, dim3((n_chains + 63) / 64), dim3(64), 0, st, n_chains, loss_next, bad, u, loss_prev, accept,
                      loss_rec, acc_rec, rec_stride);
+  return hipGetLastError();
+}
+
+// Philox mode: the draws of one iteration of one chain (gsm.h: gsm_sgs_draw_philox), one 64-lane workgroup per (iteration, chain)
+constexpr uint32_t kStreamSgs = 4;
+__global__ __launch_bounds__(64) void sgs_draw_kernel(const SgsDrawArgs a) {
+  __shared__ double mt[kMathTabDoubles];
+  __shared__ uint32_t key[kSgsMaxWin];
+  __shared__ int geo[8];
+  const int chain = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+  const int64_t rec = (int64_t)j * a.n_chains + chain, it = a.iter0 + j;
+  const uint64_t seed = a.seeds[chain];
+  for (int i = lane; i < kMathTabDoubles; i += 64) mt[i] = a.mathtab[i];
+  if (lane == 0) {
+    int row = 0, col = 0;
+    for (int att = 0; att < 64; ++att) {
+      const u32x4 r = philox_draw(seed, it, kStreamSgs, (uint32_t)att);
+      row = (int)__umulhi(r.x, (uint32_t)a.H); col = (int)__umulhi(r.y, (uint32_t)a.W);
+      if (!a.region_mask || a.region_mask[row * a.W + col] == 1) break;
+      if (att == 63) atomicOr(a.err, 16);
+    }
+    const u32x4 r = philox_draw(seed, it, kStreamSgs, 64u);
+    const int bsx = a.min_x + (int)__umulhi(r.x, (uint32_t)(a.max_x - a.min_x));
+    const int bsy = a.min_y + (int)__umulhi(r.y, (uint32_t)(a.max_y - a.min_y));
+    // int(ix -/+ bs / 2) of MCMC.py:1758-1761 (truncation towards zero of a half-integer)
+    const int r0 = max(0, (2 * row - bsx) / 2), r1 = min(a.H, (2 * row + bsx) / 2);
+    const int c0 = max(0, (2 * col - bsy) / 2), c1 = min(a.W, (2 * col + bsy) / 2);
+    a.win[4 * rec] = r0; a.win[4 * rec + 1] = r1; a.win[4 * rec + 2] = c0; a.win[4 * rec + 3] = c1;
+    a.blk[4 * rec] = row; a.blk[4 * rec + 1] = col; a.blk[4 * rec + 2] = bsx; a.blk[4 * rec + 3] = bsy;
+    a.u[rec] = u01_from(r.z, r.w);
+    geo[0] = r0; geo[1] = r1; geo[2] = c0; geo[3] = c1;
+  }
+  __syncthreads();
+  const int r0 = geo[0], r1 = geo[1], c0 = geo[2], c1 = geo[3];
+  const int ww = c1 - c0, n = max(0, r1 - r0) * max(0, ww);
+  if (lane == 0) { a.cell_off[rec] = (int32_t)(rec * a.max_cells); a.cell_cnt[rec] = (n <= a.max_cells && n <= kSgsMaxWin) ? n : 0; }
+  if (n > a.max_cells || n > kSgsMaxWin) { if (lane == 0) atomicOr(a.err, 1); return; }
+  for (int p = lane; p < n; p += 64) key[p] = philox_draw(seed, it, kStreamSgs, 128u + (uint32_t)p).x;
+  __syncthreads();
+  for (int p = lane; p < n; p += 64) {
+    const uint32_t kp = key[p];
+    int rank = 0;
+    for (int q = 0; q < n; ++q) { const uint32_t kq = key[q]; rank += (kq < kp || (kq == kp && q < p)) ? 1 : 0; }
+    const int i = r0 + p / ww, jj = c0 + p % ww;
+    const int64_t o = rec * a.max_cells + rank;
+    a.cells[2 * o] = i; a.cells[2 * o + 1] = jj;
+    double g1, g2;
+    normals2(seed, it, kStreamSgs, 2048u + (uint32_t)(p >> 1), g1, g2, mt);
+    a.z[o] = a.is_data[i * a.W + jj] ? 0.0 : ((p & 1) ? g2 : g1);
+  }
+}
+hipError_t launch_sgs_draw(const SgsDrawArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(sgs_draw_kernel, dim3(a.n_chains, a.n_iters), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 

@@ -175,6 +175,22 @@ class chain_sgs_gpu:
             raise ValueError('Seed should be an integer, a NumPy random Generator, or None')
         self.rng = rng
 
+    def set_rng_mode(self, mode):
+        """'replay' (default): the draws come from chain.rng in the reference's order (MCMC.py:1750-1797) -- accept masks and
+        beds follow the reference on the same seed.  'philox': the draws are made on the device from Philox4x32-10 counters
+        keyed by the chain's seed (gsm_sgs_draw_philox) -- no host work per iteration; a chain of its own definition, restated
+        by oracle/sgs_philox_oracle.py."""
+        if mode not in ('replay', 'philox'):
+            raise ValueError("rng mode must be 'replay' or 'philox'")
+        self.rng_mode = mode
+        self.philox_iter = 0
+
+    def _philox_seed(self):
+        seed = getattr(self, 'rng_seed', None)
+        if seed is None:
+            seed = int(self.rng.bit_generator.seed_seq.entropy) if hasattr(self.rng.bit_generator, 'seed_seq') else 0
+        return int(seed) & 0xFFFFFFFFFFFFFFFF
+
     def loss(self, massConvResidual, dataDiff):
         loss_mc = np.nansum(np.square(massConvResidual[self.mc_region_mask == 1])) / (2 * self.sigma_mc ** 2)
         return loss_mc + 0, loss_mc, 0
@@ -213,8 +229,12 @@ class chain_sgs_gpu:
         loss_mc_cache, loss_data_cache, loss_cache, step_cache, resampled_times, blocks_cache[, sample_values])."""
         if not hasattr(self, 'rng'):
             self.set_random_generator(getattr(self, 'rng_seed', None))
+        philox = getattr(self, 'rng_mode', 'replay') == 'philox'
         out, _ = run_many_sgs(self, [self.initial_bed], [self.rng], n_iter, only_save_last_bed=only_save_last_bed,
-                              info_per_iter=info_per_iter, progress_bar=progress_bar)
+                              info_per_iter=info_per_iter, progress_bar=progress_bar,
+                              philox_seeds=[self._philox_seed()] if philox else None, philox_iter0=getattr(self, 'philox_iter', 0))
+        if philox:
+            self.philox_iter += int(n_iter)
         return out[0]
 
 
@@ -222,9 +242,12 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, info_per_iter=100, progress_bar=None, device=None):
+def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, info_per_iter=100, progress_bar=None, device=None,
+                 philox_seeds=None, philox_iter0=0):
     """n small-scale chains of one template (same static fields, variogram, block sizes) in ONE handle.  rngs: one NumPy
-    Generator per chain (consumed exactly as chain_sgs.run consumes chain.rng).  Returns (list of result tuples, rngs)."""
+    Generator per chain (consumed exactly as chain_sgs.run consumes chain.rng).  philox_seeds (one 64-bit key per chain): Philox
+    mode -- the draws of iterations philox_iter0 .. are made on the device and rngs are not touched.
+    Returns (list of result tuples, rngs)."""
     import torch
     from .engine import GsmEngine
     H, W = chain.xx.shape
@@ -299,8 +322,60 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
         # to the host before the next one: the draws do not depend on the chain state (chain_sgs.run consumes chain.rng in
         # the same order whatever is accepted), so a batch of iterations is drawn ahead, uploaded once, and simulated /
         # scored / decided (gsm_sgs_decide) / committed on the device back to back.
+        philox = philox_seeds is not None
+        if philox and (host_nst is not None or keep_all or track):
+            raise NotImplementedError("Philox mode of the small-scale chain keeps the whole iteration on the device: it needs "
+                                      "only_save_last_bed=True, no sample locations and no host-side transformer")
         batch = int(os.environ.get('GSM_SGS_BATCH', '32')) if (host_nst is None and not keep_all and not track) else 1
+        if philox:
+            batch = max(batch, 2)
+            if len(philox_seeds) != n:
+                raise ValueError('need one Philox seed per chain')
+            d_seeds = torch.as_tensor(np.asarray([int(x) & 0xFFFFFFFFFFFFFFFF for x in philox_seeds], dtype=np.uint64).view(np.int64)).to(dev)
+            d_region = torch.as_tensor(np.ascontiguousarray(chain.region_mask == 1, dtype=np.uint8)).to(dev) if chain.update_in_region else None
+            d_isdata = torch.as_tensor(np.ascontiguousarray(cond_is_data, dtype=np.uint8)).to(dev)
+            max_cells = min(1024, max(1, (int(chain.block_max_x) - 1) * (int(chain.block_max_y) - 1)))
         it_done = 0
+        while philox and it_done < n_iter:
+            kb = min(batch, n_iter - it_done)
+            i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+            d_win, d_blk, d_off, d_cnt = i32(kb, n, 4), i32(kb, n, 4), i32(kb, n), i32(kb, n)
+            d_cells = i32(kb * n * max_cells, 2); d_z = torch.empty(kb * n * max_cells, dtype=torch.float64, device=dev)
+            d_us = torch.empty((kb, n), dtype=torch.float64, device=dev)
+            d_lrec = torch.empty((n, kb), dtype=torch.float64, device=dev); d_arec = torch.empty((n, kb), dtype=torch.uint8, device=dev)
+            if it_done == 0:
+                d_lprev = f64(loss_prev); d_acc = torch.empty(n, dtype=torch.uint8, device=dev)
+            at = lambda t, off_elems: C.c_void_p(t.data_ptr() + int(off_elems) * t.element_size())
+            with torch.cuda.device(dev):
+                eng._check(lib.gsm_sgs_draw_philox(h, _ptr(d_seeds), int(philox_iter0) + it_done, kb, _ptr(d_region), _ptr(d_isdata),
+                                                   int(chain.block_min_x), int(chain.block_max_x), int(chain.block_min_y), int(chain.block_max_y),
+                                                   max_cells, _ptr(d_win), _ptr(d_blk), _ptr(d_off), _ptr(d_cnt), _ptr(d_cells), _ptr(d_z),
+                                                   _ptr(d_us), eng._stream()))
+                for j in range(kb):
+                    if dev_qt:
+                        qt(cur, nxt, 0)
+                    eng._check(lib.gsm_sgs_blocks_batch(h, _ptr(nxt), _ptr(d_zcond), at(d_win, 4 * n * j), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), hw,
+                                                        rad, npts, float(vario["sill"]), at(d_off, n * j), at(d_cnt, n * j), _ptr(d_cells), _ptr(d_z),
+                                                        eng._stream()))
+                    if dev_qt:
+                        qt(nxt, prop, 1)
+                    eng._check(lib.gsm_sgs_loss(h, _ptr(prop if dev_qt else nxt), _ptr(d_trend), _ptr(d_loss), _ptr(d_bad), eng._stream()))
+                    eng._check(lib.gsm_sgs_decide(h, _ptr(d_loss), _ptr(d_bad), at(d_us, n * j), _ptr(d_lprev), _ptr(d_acc),
+                                                  at(d_lrec, j), at(d_arec, j), kb, eng._stream()))
+                    if dev_qt:
+                        eng._check(lib.gsm_sgs_commit_map(h, _ptr(cur), _ptr(prop), _ptr(resampled), at(d_win, 4 * n * j), _ptr(d_acc), eng._stream()))
+                    else:
+                        eng._check(lib.gsm_sgs_commit(h, _ptr(cur), _ptr(nxt), _ptr(resampled), at(d_win, 4 * n * j), _ptr(d_acc), eng._stream()))
+                eng._check(lib.gsm_sgs_check(h, eng._stream()))
+            loss_cache[:, it_done:it_done + kb] = d_lrec.cpu().numpy()
+            step_cache[:, it_done:it_done + kb] = d_arec.cpu().numpy()
+            blocks_cache[:, it_done:it_done + kb] = d_blk.cpu().numpy().transpose(1, 0, 2)
+            it_done += kb
+            if progress_bar is not None:
+                el = time.time() - t0
+                print(f"Chain {getattr(chain, 'chain_id', 0)} ({str(getattr(chain, 'seed', 'Unknown'))[:6]}): "
+                      f"{100 * (it_done - 1) / max(n_iter - 1, 1):3.0f}% | it/s: {it_done / max(el, 1e-9):7.2f} | n: {n_iter} | "
+                      f"loss: {loss_cache[0, it_done - 1]:.3e} | acc: {step_cache[0, :it_done].sum() / it_done:.4f}", file=sys.stdout, flush=True)
         while batch > 1 and it_done < n_iter:
             kb = min(batch, n_iter - it_done)
             wins = np.empty((kb, n, 4), np.int32); offs = np.zeros((kb, n + 1), np.int32); us = np.empty((kb, n))
@@ -329,9 +404,9 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                 for j in range(kb):
                     if dev_qt:
                         qt(cur, nxt, 0)                       # the whole map to normal scores (MCMC.py:1766)
-                    eng._check(lib.gsm_sgs_blocks(h, _ptr(nxt), _ptr(d_zcond), at(d_win, 4 * n * j), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), hw,
-                                                  rad, npts, float(vario["sill"]), at(d_off, (n + 1) * j), at(d_cells, 2 * bases[j]),
-                                                  at(d_z, bases[j]), None, eng._stream()))
+                    eng._check(lib.gsm_sgs_blocks_batch(h, _ptr(nxt), _ptr(d_zcond), at(d_win, 4 * n * j), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), hw,
+                                                        rad, npts, float(vario["sill"]), at(d_off, (n + 1) * j), None, at(d_cells, 2 * bases[j]),
+                                                        at(d_z, bases[j]), eng._stream()))
                     if dev_qt:
                         qt(nxt, prop, 1)                      # ... and back (MCMC.py:1777)
                     eng._check(lib.gsm_sgs_loss(h, _ptr(prop if dev_qt else nxt), _ptr(d_trend), _ptr(d_loss), _ptr(d_bad), eng._stream()))
@@ -341,6 +416,7 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                         eng._check(lib.gsm_sgs_commit_map(h, _ptr(cur), _ptr(prop), _ptr(resampled), at(d_win, 4 * n * j), _ptr(d_acc), eng._stream()))
                     else:
                         eng._check(lib.gsm_sgs_commit(h, _ptr(cur), _ptr(nxt), _ptr(resampled), at(d_win, 4 * n * j), _ptr(d_acc), eng._stream()))
+                eng._check(lib.gsm_sgs_check(h, eng._stream()))
             loss_cache[:, it_done:it_done + kb] = d_lrec.cpu().numpy()
             step_cache[:, it_done:it_done + kb] = d_arec.cpu().numpy()
             it_done += kb

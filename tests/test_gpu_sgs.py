@@ -217,3 +217,50 @@ def test_device_quantile_transformer_equals_sklearn():
             np.testing.assert_allclose(d_x.cpu().numpy(), want_i, rtol=0, atol=1e-9, equal_nan=True)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("transform", [False, True])
+def test_philox_mode_chain_equals_its_oracle(transform):
+    """Philox mode of the small-scale chain (draws on the device, gsm_sgs_draw_philox; the whole chain without host work per
+    iteration) against oracle/sgs_oracle.py driven by oracle/sgs_philox_oracle.PhiloxSgsRng: blocks, accept masks and
+    resampled counts identical, losses and beds to the tolerance of the kriging solve; two run() calls continue the counters."""
+    import sgs_philox_oracle as spo
+    from mcmc_gpu_amd import sgs
+    H, n_iter = 32, 48        # (see DESIGN 8: where a sector holds equidistant candidates beyond its quota the reference's order is
+    prob = sc.problem(H)      #  NumPy's unstable argsort; with this seed that first happens at iteration 52)
+    sill = float(np.var(prob["bed"]))
+    nst = None
+    if transform:
+        from sklearn.preprocessing import QuantileTransformer
+        nst = QuantileTransformer(n_quantiles=300, output_distribution="normal", random_state=1, subsample=None).fit(prob["bed"].reshape(-1, 1))
+        sill = 1.0
+    grounded = np.ones((H, H), dtype=int)
+    cfg = so.SgsConfig(prob["xx"], prob["yy"], prob["surf"], prob["velx"], prob["vely"], prob["dhdt"], prob["smb"], prob["cond_bed"],
+                       prob["data_mask"], grounded, prob["region_mask"], prob["resolution"], 60.0,
+                       [0, 0.0, 6000.0, 6000.0, sill, "Exponential", None], [16, 4000.0, False, 0], 3, 8, 3, 8, nst_trans=nst)
+    seed = 2 ** 40 + 77
+    ref = so.run_chain_sgs(cfg, prob["bed"], n_iter, spo.PhiloxSgsRng(seed, ~np.isnan(prob["cond_bed"])))
+    ch = sgs.chain_sgs_gpu(prob["xx"], prob["yy"], prob["bed"], prob["surf"], prob["velx"], prob["vely"], prob["dhdt"], prob["smb"],
+                           prob["cond_bed"], prob["data_mask"], grounded, prob["resolution"])
+    ch.set_update_region(True, prob["region_mask"]); ch.set_loss_type(sigma_mc=60.0, massConvInRegion=True)
+    ch.set_normal_transformation(nst, do_transform=transform); ch.set_trend(None, detrend_map=False)
+    ch.set_variogram("Exponential", 6000.0, sill, 0.0, isotropic=True); ch.set_sgs_param(16, 4000.0); ch.set_block_sizes(3, 8, 3, 8)
+    ch.set_random_generator(rng_seed=seed)
+    ch.set_rng_mode('philox')
+    out = ch.run(n_iter, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None)
+    assert np.array_equal(out[6], ref[6]), "blocks"
+    assert np.array_equal(out[4], ref[4]), "accept masks"
+    assert np.array_equal(out[5], ref[5]), "resampled counts"
+    np.testing.assert_allclose(out[3], ref[3], rtol=1e-9)
+    np.testing.assert_allclose(out[0], ref[0], rtol=0, atol=1e-7 if not transform else 1e-6)
+    assert 0.05 < out[4].mean() < 0.98
+    # a second segment continues the iteration counter: equal to one run of both lengths
+    ch2 = sgs.chain_sgs_gpu(prob["xx"], prob["yy"], prob["bed"], prob["surf"], prob["velx"], prob["vely"], prob["dhdt"], prob["smb"],
+                            prob["cond_bed"], prob["data_mask"], grounded, prob["resolution"])
+    ch2.__dict__.update({k: v for k, v in ch.__dict__.items() if k not in ("initial_bed",)})
+    ch2.initial_bed = prob["bed"]; ch2.philox_iter = 0
+    a = ch2.run(30, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None)
+    ch2.initial_bed = a[0]
+    b = ch2.run(18, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None)
+    assert np.array_equal(np.concatenate([a[4], b[4]]), out[4]) and np.array_equal(np.concatenate([a[6], b[6]]), out[6])
+    np.testing.assert_allclose(b[0], out[0], rtol=0, atol=1e-9)
