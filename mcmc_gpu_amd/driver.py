@@ -331,12 +331,20 @@ def msc_run_wrapper(param_chain, param_run):
 
 
 def smallScaleChain_mp(n_chains, n_workers, smallScaleChain, initial_beds, ssc_rng_seeds, lsc_rng_seed, n_iters,
-                       output_path='./Data/output'):
+                       output_path='./Data/output', mode=None):
     """Run n_chains small-scale chains and return the list of their result tuples (reference :211-274); files under
     <output_path>/LargeScaleChain/<lsc seed>/SmallScaleChain/<ssc seed>/ as the reference writes them.  Chains that share
     n_iter run together in one libgsm_hip handle (one workgroup per chain in every launch); `n_workers` is accepted for
-    signature compatibility (the reference's pool size) and not used."""
+    signature compatibility (the reference's pool size) and not used.
+
+    mode 'replay' (default, or smallScaleChain.rng_mode): each chain draws from numpy.random.default_rng(its seed) as the
+    reference's workers do -- results and files follow the CPU driver.  mode 'philox': the draws are made on the device (Philox
+    counters keyed by the chain's seed, continuing at the iteration count of the seed folder's checkpoint): no host work per
+    iteration."""
     from . import sgs
+    philox = (mode or getattr(smallScaleChain, 'rng_mode', 'replay')) == 'philox'
+    if mode not in (None, 'replay', 'philox'):
+        raise ValueError("mode must be 'replay' or 'philox'")
     tic = time.time()
     base = Path(output_path) / 'LargeScaleChain' / str(lsc_rng_seed)[:6] / 'SmallScaleChain'
     if len(set(int(v) for v in n_iters[:n_chains])) == 1 and n_chains > 0:
@@ -345,10 +353,17 @@ def smallScaleChain_mp(n_chains, n_workers, smallScaleChain, initial_beds, ssc_r
         prevs = [_msc_load_previous(f) for f in folders]
         beds = [p['bed'] if p else initial_beds[i] for i, p in enumerate(prevs)]
         rngs = [np.random.default_rng(seed=ssc_rng_seeds[i]) for i in range(n_chains)]
-        result, _ = sgs.run_many_sgs(smallScaleChain, beds, rngs, n_iter, only_save_last_bed=True, info_per_iter=10, progress_bar=None)
+        starts = set(p['cumulative'] if p else 0 for p in prevs)
+        if philox and len(starts) != 1:
+            raise ValueError('Philox mode runs the chains of a call in lock-step: their seed folders must hold the same iteration count')
+        result, _ = sgs.run_many_sgs(smallScaleChain, beds, rngs, n_iter, only_save_last_bed=True, info_per_iter=10, progress_bar=None,
+                                     philox_seeds=[int(v) for v in ssc_rng_seeds[:n_chains]] if philox else None,
+                                     philox_iter0=starts.pop() if philox else 0)
         for i in range(n_chains):
             _msc_save(folders[i], result[i], n_iter, prevs[i])
     else:
+        if philox:
+            raise ValueError('Philox mode needs the same n_iter for every chain of a call')
         result = []
         for i in range(n_chains):
             cp = deepcopy(smallScaleChain.__dict__)

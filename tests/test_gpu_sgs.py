@@ -264,3 +264,20 @@ def test_philox_mode_chain_equals_its_oracle(transform):
     b = ch2.run(18, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None)
     assert np.array_equal(np.concatenate([a[4], b[4]]), out[4]) and np.array_equal(np.concatenate([a[6], b[6]]), out[6])
     np.testing.assert_allclose(b[0], out[0], rtol=0, atol=1e-9)
+
+
+def test_small_scale_driver_philox_mode_segments(tmp_path):
+    """smallScaleChain_mp(mode='philox'): two 1000-iteration segments (the second resumes from the seed folders' files and
+    continues the Philox iteration counter) equal one 2000-iteration call."""
+    from mcmc_gpu_amd import driver, sgs, synthetic
+    prob, ch = synthetic.sgs_template(32, transform=False)
+    beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(3)]
+    seeds = [811, 822, 833]
+    one = driver.smallScaleChain_mp(3, 1, ch, beds, seeds, 5, [2000] * 3, output_path=str(tmp_path / "one"), mode='philox')
+    driver.smallScaleChain_mp(3, 1, ch, beds, seeds, 5, [1000] * 3, output_path=str(tmp_path / "two"), mode='philox')
+    two = driver.smallScaleChain_mp(3, 1, ch, beds, seeds, 5, [1000] * 3, output_path=str(tmp_path / "two"), mode='philox')
+    for c in range(3):
+        assert np.array_equal(one[c][4][1000:], two[c][4]) and np.array_equal(one[c][6][1000:], two[c][6])
+        np.testing.assert_allclose(one[c][0], two[c][0], rtol=0, atol=1e-6)     # the bed passes through a text file between segments
+    f = tmp_path / "two" / "LargeScaleChain" / "5" / "SmallScaleChain" / "811"
+    assert np.loadtxt(f / "steps_2k.txt").shape == (2000,)
