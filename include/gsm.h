@@ -168,7 +168,7 @@ int gsm_spectral_from_noise(gsm_handle h, int32_t n_fields, const int32_t* size_
 
 /* Philox mode end to end.  Spectral generator: the fused chain kernel (per chain-step the proposal is generated and
  * consumed inside one workgroup; nothing but chain state touches HBM), launched once per segment of at most 4096 steps
- * (scratch: one 124-byte scalar record per chain and step of a SEGMENT; `batch` is not used).  Cholesky generator, block
+ * (scratch: one 140-byte scalar record per chain and step of a SEGMENT; `batch` is not used).  Cholesky generator, block
  * tables beyond the fused kernel's LDS budget, or GSM_FUSED=0 in the environment: batches of `batch` steps, proposals of
  * batch k+1 generated on a second stream while batch k is stepped, scratch owned by the handle.
  * Both forms give bit-identical results, whatever the segment / batch size.  Outputs as gsm_run_replay plus blocks

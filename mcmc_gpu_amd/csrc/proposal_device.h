@@ -112,8 +112,7 @@ __device__ __forceinline__ double spectral_amp(const gsm_rf_params& P, const Pro
 // The proposal is a sequence of stages, each a function below; a stage is executed by NW waves of the workgroup and `w`
 // is the calling wave's index among them (tile / unit ownership: unit u belongs to wave u mod NW).  Callers:
 //   propose_field<NT>        all NT / 64 waves run every stage in turn (stand-alone proposal kernel, gsm_spectral_from_noise)
-//   chain_fused_kernel       12 waves run the matrix-core stages of step s while the other 4 compute the coefficients of
-//                            step s + 1 (chain_fused_kernel.hip)
+//   chain_fused_kernel       all 16 waves run every stage in turn, with the DFT tables staged in LDS (chain_fused_kernel.hip)
 // The arithmetic of every field value -- including the order of the two reductions of the standardisation -- does not
 // depend on NW, so all forms produce bit-identical fields.
 //
