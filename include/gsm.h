@@ -235,8 +235,8 @@ int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* const* factor
  *                                       rng.normal(est, sqrt(var)) = est + sqrt(var) * z (MCMC.py:165)
  *   trace    [dev, total*3] or NULL     (number of neighbours, kriging estimate, kriging variance) per cell; -1 neighbours =
  *                                       cell was conditioned already
- * num_points in [8, 48] (num_points / 8 per octant).  The kriging systems are solved by elimination with partial pivoting
- * where the reference calls numpy.linalg.lstsq: estimates agree to ~1e-10 relative, not bit for bit.  A cell with no
+ * num_points in [8, 48] (num_points / 8 per octant).  The kriging systems are solved by Gauss-Jordan elimination on the diagonal
+ * (the covariance block is symmetric positive definite) where the reference calls numpy.linalg.lstsq: estimates agree to ~1e-10 relative, not bit for bit.  A cell with no
  * neighbour within `radius` (the reference would widen the search by 100 km, MCMC.py:152-156) returns GSM_E_UNSUPPORTED.
  * Synchronises the stream.
  * Replaces: sgs (MCMC.py:91-173), neighbors (gstatsim_custom/neighbors.py:4-64), ok_solve (gstatsim_custom/_krige.py:5-44). */

@@ -239,26 +239,17 @@ __global__ __launch_bounds__(64) void sgs_blocks_kernel(const SgsArgs a) {
     const double rho_l = (lane < n) ? A[lane * kSgsStride + N] : 0.0;            // kept: the elimination overwrites it
     bool singular = false;
     for (int kk = 0; kk < N; ++kk) {
-      const double mine = (lane >= kk && lane < N) ? fabs(A[lane * kSgsStride + kk]) : -1.0;
-      const double mx = -wave_min_f64(-mine);
-      const int piv = wave_min_i32((mine == mx) ? lane : 0x7fffffff);
-      if (!(mx > 0.0)) { singular = true; break; }
-      if (piv != kk && lane <= N) {
-        const double t = A[kk * kSgsStride + lane];
-        A[kk * kSgsStride + lane] = A[piv * kSgsStride + lane];
-        A[piv * kSgsStride + lane] = t;
-      }
-      __syncthreads();
-      // row update: lane = (row slot, column slot) of a 16 x 4 arrangement; a lane takes every fourth column of its rows --
-      // the same a - f * b per entry, f = A[row][kk] / pivot, as a row-at-a-time loop
+      // pivot = the diagonal entry: the leading n x n block is a covariance matrix (symmetric positive definite), whose
+      // elimination needs no row exchanges, and the last pivot is -1' Sigma^-1 1 < 0
       const double pv = A[kk * kSgsStride + kk];
+      if (!(fabs(pv) > 0.0)) { singular = true; break; }
+      // row update: lane = (row slot, column slot) of a 16 x 4 arrangement; a lane takes every fourth column (beyond kk: column
+      // kk itself is not read again) of its rows: a - f * b per entry, f = A[row][kk] / pivot.  One barrier per step.
       for (int row = lane >> 2; row < N; row += 16) {
         if (row == kk) continue;
         const double f = A[row * kSgsStride + kk] / pv;
         for (int c = kk + 1 + (lane & 3); c <= N; c += 4) A[row * kSgsStride + c] -= f * A[kk * kSgsStride + c];
       }
-      __syncthreads();
-      if (lane < N && lane != kk) A[lane * kSgsStride + kk] = 0.0;
       __syncthreads();
     }
     if (singular) {
