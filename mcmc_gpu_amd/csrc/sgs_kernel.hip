@@ -20,7 +20,7 @@
 //     (NumPy's masked C order followed by a stable sort; numpy.argsort's default sort is stable below 17 elements).
 //   2 ordinary kriging: (n+1) x (n+1) system [Sigma 1; 1^T 0] w = [rho; 1], covariances from a table indexed by the integer
 //     lag between two cells (the host evaluates the reference's covariance model -- scipy's Bessel K for Matern -- once per
-//     lag), solved in LDS by Gauss-Jordan elimination with partial pivoting in fp64 (the reference calls numpy.linalg.lstsq,
+//     lag), solved in LDS by Gauss-Jordan elimination on the diagonal (positive-definite covariance block) in fp64 (the reference calls numpy.linalg.lstsq,
 //     an SVD solve: same solution for these non-singular systems, different rounding -- the stated tolerance of this path).
 //   3 value = est + sqrt(|var|) * z; the cell becomes conditioning data for the cells after it.
 // Limits: hw <= 16 (search window 33 x 33), num_points <= 48, window (block) cells <= 1024.  A cell without any neighbour
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64) void sgs_blocks_kernel(const SgsArgs a) {
       if (lane == 0) { atomicOr(a.err, 4); overlay[op] = NAN; }
       continue;
     }
-    // ---- 2 ordinary kriging system, Gauss-Jordan with partial pivoting ---------------------------------
+    // ---- 2 ordinary kriging system, Gauss-Jordan elimination on the diagonal ----------------------------
     const int N = n + 1;
     for (int e = lane; e < N * (N + 1); e += 64) {
       const int ra = e / (N + 1), cb = e % (N + 1);
