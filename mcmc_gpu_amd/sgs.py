@@ -376,14 +376,15 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                 print(f"Chain {getattr(chain, 'chain_id', 0)} ({str(getattr(chain, 'seed', 'Unknown'))[:6]}): "
                       f"{100 * (it_done - 1) / max(n_iter - 1, 1):3.0f}% | it/s: {it_done / max(el, 1e-9):7.2f} | n: {n_iter} | "
                       f"loss: {loss_cache[0, it_done - 1]:.3e} | acc: {step_cache[0, :it_done].sum() / it_done:.4f}", file=sys.stdout, flush=True)
-        while batch > 1 and it_done < n_iter:
-            kb = min(batch, n_iter - it_done)
+        # Replay batches: the host draws of batch b + 1 are made while the device works on batch b (its launches are
+        # asynchronous; gsm_sgs_check and the record download of batch b come after the draws of b + 1).
+        def host_draws(it0, kb):
             wins = np.empty((kb, n, 4), np.int32); offs = np.zeros((kb, n + 1), np.int32); us = np.empty((kb, n))
             cells, zs, bases = [], [], np.zeros(kb + 1, np.int64)
             for c in range(n):                     # per chain in iteration order: each chain owns its generator
                 for j in range(kb):
                     blk, win, inds, z, us[j, c] = chain._draw_iteration(rngs[c], cond_is_data)
-                    blocks_cache[c, it_done + j] = blk
+                    blocks_cache[c, it0 + j] = blk
                     wins[j, c] = win
                     cells.append((j, c, inds)); zs.append((j, c, z))
             cells.sort(key=lambda t: (t[0], t[1])); zs.sort(key=lambda t: (t[0], t[1]))
@@ -393,12 +394,15 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                     offs[j, c + 1] = offs[j, c] + cells[k][2].shape[0]; k += 1
                 bases[j + 1] = bases[j] + offs[j, n]
             tot = int(bases[kb])
-            d_win = torch.as_tensor(wins).to(dev); d_off = torch.as_tensor(offs).to(dev); d_us = torch.as_tensor(us).to(dev)
-            d_cells = torch.as_tensor(np.ascontiguousarray(np.concatenate([t[2] for t in cells]) if tot else np.zeros((1, 2), np.int32))).to(dev)
-            d_z = torch.as_tensor(np.concatenate([t[2] for t in zs]) if tot else np.zeros(1)).to(dev)
+            cells_all = np.ascontiguousarray(np.concatenate([t[2] for t in cells]) if tot else np.zeros((1, 2), np.int32))
+            z_all = np.concatenate([t[2] for t in zs]) if tot else np.zeros(1)
+            return dict(it0=it0, kb=kb, wins=wins, offs=offs, us=us, bases=bases, cells=cells_all, z=z_all)
+
+        def launch(d):
+            kb, bases = d['kb'], d['bases']
+            d_win = torch.as_tensor(d['wins']).to(dev); d_off = torch.as_tensor(d['offs']).to(dev); d_us = torch.as_tensor(d['us']).to(dev)
+            d_cells = torch.as_tensor(d['cells']).to(dev); d_z = torch.as_tensor(d['z']).to(dev)
             d_lrec = torch.empty((n, kb), dtype=torch.float64, device=dev); d_arec = torch.empty((n, kb), dtype=torch.uint8, device=dev)
-            if it_done == 0:
-                d_lprev = f64(loss_prev); d_acc = torch.empty(n, dtype=torch.uint8, device=dev)
             at = lambda t, off_elems: C.c_void_p(t.data_ptr() + int(off_elems) * t.element_size())
             with torch.cuda.device(dev):
                 for j in range(kb):
@@ -416,15 +420,34 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                         eng._check(lib.gsm_sgs_commit_map(h, _ptr(cur), _ptr(prop), _ptr(resampled), at(d_win, 4 * n * j), _ptr(d_acc), eng._stream()))
                     else:
                         eng._check(lib.gsm_sgs_commit(h, _ptr(cur), _ptr(nxt), _ptr(resampled), at(d_win, 4 * n * j), _ptr(d_acc), eng._stream()))
+            d['keep'] = (d_win, d_off, d_us, d_cells, d_z)      # alive until the batch is finished
+            d['lrec'], d['arec'] = d_lrec, d_arec
+
+        def finish(d):
+            with torch.cuda.device(dev):
                 eng._check(lib.gsm_sgs_check(h, eng._stream()))
-            loss_cache[:, it_done:it_done + kb] = d_lrec.cpu().numpy()
-            step_cache[:, it_done:it_done + kb] = d_arec.cpu().numpy()
-            it_done += kb
+            it0, kb = d['it0'], d['kb']
+            loss_cache[:, it0:it0 + kb] = d['lrec'].cpu().numpy()
+            step_cache[:, it0:it0 + kb] = d['arec'].cpu().numpy()
             if progress_bar is not None:
+                done = it0 + kb
                 el = time.time() - t0
                 print(f"Chain {getattr(chain, 'chain_id', 0)} ({str(getattr(chain, 'seed', 'Unknown'))[:6]}): "
-                      f"{100 * (it_done - 1) / max(n_iter - 1, 1):3.0f}% | it/s: {it_done / max(el, 1e-9):7.2f} | n: {n_iter} | "
-                      f"loss: {loss_cache[0, it_done - 1]:.3e} | acc: {step_cache[0, :it_done].sum() / it_done:.4f}", file=sys.stdout, flush=True)
+                      f"{100 * (done - 1) / max(n_iter - 1, 1):3.0f}% | it/s: {done / max(el, 1e-9):7.2f} | n: {n_iter} | "
+                      f"loss: {loss_cache[0, done - 1]:.3e} | acc: {step_cache[0, :done].sum() / done:.4f}", file=sys.stdout, flush=True)
+
+        if batch > 1 and it_done < n_iter:
+            d_lprev = f64(loss_prev); d_acc = torch.empty(n, dtype=torch.uint8, device=dev)
+            running = host_draws(0, min(batch, n_iter))
+            launch(running)
+            it_done = running['kb']
+            while it_done < n_iter:
+                nxt_draws = host_draws(it_done, min(batch, n_iter - it_done))      # overlaps the device work of `running`
+                finish(running)
+                launch(nxt_draws)
+                running = nxt_draws
+                it_done += running['kb']
+            finish(running)
         for it in range(it_done, n_iter):
             wins = np.empty((n, 4), np.int32); offs = np.zeros(n + 1, np.int32); us = np.empty(n)
             cells, zs = [], []
