@@ -211,7 +211,11 @@ __global__ __launch_bounds__(64) void sgs_blocks_kernel(const SgsArgs a) {
         }
         const double wd = wave_min_f64(best_d);
         if (wd == INFINITY) break;                                          // sector exhausted
-        const int wp = wave_min_i32((best_d == wd) ? best_p : 0x7fffffff);
+        // the smallest window position among the lanes that hold the minimum: usually one lane (then its position is read
+        // with one v_readlane), else a second reduction
+        const unsigned long long tied = __ballot(best_d == wd);
+        const int wp = (__popcll(tied) == 1) ? __builtin_amdgcn_readlane(best_p, __ffsll((long long)tied) - 1)
+                                             : wave_min_i32((best_d == wd) ? best_p : 0x7fffffff);
         if (lane == 0) {
           const int io = (int)(((uint32_t)wp * side_magic) >> 16);
           nb_i[n] = i0 - hw + io; nb_j[n] = j0 - hw + (wp - io * side); nb_val[n] = cand_v[wp];
