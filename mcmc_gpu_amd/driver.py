@@ -168,7 +168,7 @@ def _run_shard(lo, hi, largeScaleChain, rf, initial_beds, rng_seeds, n_iters, ou
     return local
 
 
-def _rank_main(rank, world, port, backend, payload_path, result_path):
+def _rank_main(rank, world, port, backend, payload_path, result_path, which='largeScaleChain_mp'):
     """Body of one self-started rank (a fresh process): rendezvous on 127.0.0.1, run the shard, all-gather, rank 0 stores
     the full result list for the parent."""
     import os
@@ -185,7 +185,7 @@ def _rank_main(rank, world, port, backend, payload_path, result_path):
         torch.cuda.set_device(rank if torch.cuda.device_count() > rank else 0)
     with open(payload_path, 'rb') as fh:
         kw = pickle.load(fh)
-    res = largeScaleChain_mp(n_gpus=1, **kw)         # inside an initialised group: runs this rank's shard, gathers
+    res = globals()[which](n_gpus=1, **kw)           # inside an initialised group: runs this rank's shard, gathers
     if rank == 0:
         with open(result_path, 'wb') as fh:
             pickle.dump(res, fh, protocol=4)
@@ -193,7 +193,7 @@ def _rank_main(rank, world, port, backend, payload_path, result_path):
     dist.destroy_process_group()
 
 
-def _self_launch(n_gpus, kw):
+def _self_launch(n_gpus, kw, which='largeScaleChain_mp'):
     """Start n_gpus ranks of this driver (fresh processes: 'spawn'), one per GPU, as the reference's driver starts its own
     pool workers (largeScaleChain_multiprocessing_GPU.py:47, :84-85); return rank 0's gathered result list."""
     import os
@@ -210,7 +210,7 @@ def _self_launch(n_gpus, kw):
         payload, result = os.path.join(td, 'payload.pkl'), os.path.join(td, 'result.pkl')
         with open(payload, 'wb') as fh:
             pickle.dump(kw, fh, protocol=4)
-        tmp_mp.spawn(_rank_main, args=(n_gpus, port, backend, payload, result), nprocs=n_gpus, join=True)   # raises if a rank fails
+        tmp_mp.spawn(_rank_main, args=(n_gpus, port, backend, payload, result, which), nprocs=n_gpus, join=True)   # raises if a rank fails
         with open(result, 'rb') as fh:
             return pickle.load(fh)
 
@@ -331,7 +331,7 @@ def msc_run_wrapper(param_chain, param_run):
 
 
 def smallScaleChain_mp(n_chains, n_workers, smallScaleChain, initial_beds, ssc_rng_seeds, lsc_rng_seed, n_iters,
-                       output_path='./Data/output', mode=None):
+                       output_path='./Data/output', mode=None, n_gpus=None):
     """Run n_chains small-scale chains and return the list of their result tuples (reference :211-274); files under
     <output_path>/LargeScaleChain/<lsc seed>/SmallScaleChain/<ssc seed>/ as the reference writes them.  Chains that share
     n_iter run together in one libgsm_hip handle (one workgroup per chain in every launch); `n_workers` is accepted for
@@ -345,6 +345,28 @@ def smallScaleChain_mp(n_chains, n_workers, smallScaleChain, initial_beds, ssc_r
     philox = (mode or getattr(smallScaleChain, 'rng_mode', 'replay')) == 'philox'
     if mode not in (None, 'replay', 'philox'):
         raise ValueError("mode must be 'replay' or 'philox'")
+    # n_gpus as in largeScaleChain_mp: the chains are independent, so they are sharded contiguously over the ranks (one per
+    # GPU, started here when the caller brought no launcher) and the result tuples are gathered at the end
+    import os
+    import torch.distributed as dist
+    sharded = n_gpus != -1 and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if n_gpus != -1 and not sharded and 'RANK' not in os.environ:
+        import torch
+        if n_gpus is None:
+            n_gpus = max(1, torch.cuda.device_count())
+        n_gpus = max(1, min(int(n_gpus), int(n_chains)))
+        if n_gpus > 1:
+            return _self_launch(n_gpus, dict(n_chains=n_chains, n_workers=n_workers, smallScaleChain=smallScaleChain, initial_beds=initial_beds,
+                                             ssc_rng_seeds=ssc_rng_seeds, lsc_rng_seed=lsc_rng_seed, n_iters=n_iters,
+                                             output_path=output_path, mode=mode), which='smallScaleChain_mp')
+    if sharded:
+        rank, world = dist.get_rank(), dist.get_world_size()
+        lo, hi = parallel.shard_bounds(n_chains, world, rank)
+        local = smallScaleChain_mp(hi - lo, n_workers, smallScaleChain, list(initial_beds[lo:hi]), list(ssc_rng_seeds[lo:hi]), lsc_rng_seed,
+                                   list(n_iters[lo:hi]), output_path=output_path, mode=mode, n_gpus=-1) if hi > lo else []
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+        return [r for part in gathered for r in part]
     tic = time.time()
     base = Path(output_path) / 'LargeScaleChain' / str(lsc_rng_seed)[:6] / 'SmallScaleChain'
     if len(set(int(v) for v in n_iters[:n_chains])) == 1 and n_chains > 0:

@@ -281,3 +281,20 @@ def test_small_scale_driver_philox_mode_segments(tmp_path):
         np.testing.assert_allclose(one[c][0], two[c][0], rtol=0, atol=1e-6)     # the bed passes through a text file between segments
     f = tmp_path / "two" / "LargeScaleChain" / "5" / "SmallScaleChain" / "811"
     assert np.loadtxt(f / "steps_2k.txt").shape == (2000,)
+
+
+def test_small_scale_driver_starts_its_own_ranks(tmp_path, monkeypatch):
+    """smallScaleChain_mp(n_gpus=2) without a launcher: two self-started ranks (sharing the box's one GPU, gloo instead of RCCL)
+    take contiguous shards of the chains and the results are gathered -- equal to the single-process run in both draw modes."""
+    from mcmc_gpu_amd import driver, synthetic
+    monkeypatch.setenv("GSM_DIST_BACKEND", "gloo")
+    prob, ch = synthetic.sgs_template(32, transform=False)
+    beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(5)]
+    seeds = [911, 922, 933, 944, 955]
+    for mode in ("philox", "replay"):
+        one = driver.smallScaleChain_mp(5, 1, ch, beds, seeds, 5, [1000] * 5, output_path=str(tmp_path / f"one_{mode}"), mode=mode, n_gpus=1)
+        two = driver.smallScaleChain_mp(5, 1, ch, beds, seeds, 5, [1000] * 5, output_path=str(tmp_path / f"two_{mode}"), mode=mode, n_gpus=2)
+        assert len(two) == 5
+        for a, b in zip(one, two):
+            for x, y in zip(a, b):
+                assert np.array_equal(np.asarray(x, dtype=float), np.asarray(y, dtype=float), equal_nan=True)
