@@ -30,6 +30,7 @@ struct gsm_context {
   int tables_len = 0, tab_max = 0;
   double* d_k2 = nullptr;        // per-size k^2 tables of the spectral amplitude (depend on rf.resolution)
   double* d_mathtab = nullptr;   // log / sincos table of the coefficient phase (math_tables.h)
+  double* d_sgs_part_sum = nullptr; int32_t* d_sgs_part_bad = nullptr; size_t sgs_part_cap = 0;   // gsm_sgs_loss partial sums
   int32_t* d_k2_off = nullptr;
   double k2_resolution = 0.0;
   PropScalars* d_scalars[2] = {nullptr, nullptr};
@@ -131,6 +132,7 @@ extern "C" int gsm_destroy(gsm_handle h) {
   for (auto& p : h->d_scalars) if (p) hipFree(p);
   if (h->d_k2) hipFree(h->d_k2);
   if (h->d_mathtab) hipFree(h->d_mathtab);
+  if (h->d_sgs_part_sum) { hipFree(h->d_sgs_part_sum); hipFree(h->d_sgs_part_bad); }
   if (h->d_k2_off) hipFree(h->d_k2_off);
   if (h->d_factors) hipFree(h->d_factors);
   for (auto& c : h->chol) { if (c.ints) hipFree(c.ints); if (c.zoff) hipFree(c.zoff); if (c.per_rec) hipFree(c.per_rec);
@@ -862,7 +864,14 @@ extern "C" int gsm_sgs_loss(gsm_handle h, const double* beds, const double* tren
   if (h->f32_state) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_loss: fp64 beds only");
   if (!beds || !loss || !bad) return fail(h, GSM_E_ARG, "gsm_sgs_loss: NULL pointer");
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, launch_sgs_loss(h->S, h->n_chains, beds, trend, loss, bad, (hipStream_t)stream));
+  const size_t need = (size_t)h->n_chains * sgs_loss_parts(h->S);
+  if (h->sgs_part_cap < need) {
+    if (h->d_sgs_part_sum) { hipFree(h->d_sgs_part_sum); hipFree(h->d_sgs_part_bad); h->d_sgs_part_sum = nullptr; h->d_sgs_part_bad = nullptr; h->sgs_part_cap = 0; }
+    HIPCHK(h, hipMalloc(&h->d_sgs_part_sum, need * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->d_sgs_part_bad, need * sizeof(int32_t)));
+    h->sgs_part_cap = need;
+  }
+  HIPCHK(h, launch_sgs_loss(h->S, h->n_chains, beds, trend, loss, bad, h->d_sgs_part_sum, h->d_sgs_part_bad, (hipStream_t)stream));
   return GSM_OK;
 }
 

@@ -169,8 +169,9 @@ struct SgsDrawArgs {
   int32_t* err;
 };
 hipError_t launch_sgs_draw(const SgsDrawArgs& a, hipStream_t st);
+int sgs_loss_parts(const StaticFields& S);      // workgroups per chain of the loss kernel; scratch = n_chains * parts doubles + ints
 hipError_t launch_sgs_loss(const StaticFields& S, int n_chains, const double* beds, const double* trend, double* loss, int32_t* bad,
-                           hipStream_t st);
+                           double* part_sum, int32_t* part_bad, hipStream_t st);
 hipError_t launch_sgs_decide(int n_chains, const double* loss_next, const int32_t* bad, const double* u, double* loss_prev,
                              uint8_t* accept, double* loss_rec, uint8_t* acc_rec, int64_t rec_stride, hipStream_t st);
 hipError_t launch_qt(const double* quantiles, const double* references, int nq, double clip_min, double clip_max, const double* x,
