@@ -226,30 +226,45 @@ int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* const* factor
  *                                       block, NaN where there is none: z_cond_bed, MCMC.py:1771)
  *   windows  [dev, n_chains*4]          (row0, row1, col0, col1) of each chain's block; at most 1024 cells
  *   x_axis [dev, W], y_axis [dev, H]    coordinates of the columns / rows (the grid must be axis-aligned: xx[i][j] = x_axis[j])
- *   lag_cov  [dev, (4hw+1)^2]           covariance at the integer lag (di, dj), -2hw <= di, dj <= 2hw, row-major: the caller
- *                                       evaluates the variogram model (covariance.py:4-28 through make_sigma / make_rho,
- *                                       _krige.py:105-143) once per lag; hw = ceil(radius / |x_axis[1] - x_axis[0]|) <= 16
+ *   lag_cov  [dev, (2 lag_mi + 1) * (2 lag_mj + 1)]  covariance at the integer lag (di, dj), |di| <= lag_mi, |dj| <= lag_mj,
+ *                                       row-major: the caller evaluates the variogram model (covariance.py:4-28 through
+ *                                       make_sigma / make_rho, _krige.py:105-143) once per lag.  Two chosen neighbours are at
+ *                                       most 2 hw apart: lag_mi >= min(2 hw, H - 1), lag_mj >= min(2 hw, W - 1); the whole grid
+ *                                       (H - 1, W - 1) if the radius-widening fallback is to work
+ *   hw                                  search half-width in cells: ceil(radius / |x_axis[1] - x_axis[0]|), the half-width of the
+ *                                       reference's circle stencil (neighbors.py:66-83) -- any value >= 1 (the reference's driver:
+ *                                       30 km at 500 m = 60)
  *   cell_off [dev, n_chains+1], cells [dev, total*2]   the (row, col) of each chain's cells in simulation order -- the
  *                                       caller's rng.shuffle (MCMC.py:128); every cell must lie inside the chain's window
  *   z        [dev, total]               one standard normal per listed cell (used only if the cell is simulated):
  *                                       rng.normal(est, sqrt(var)) = est + sqrt(var) * z (MCMC.py:165)
+ *   max_cells                           upper bound of a chain's cell count (<= 1024): stride of the library's scratch records
  *   trace    [dev, total*3] or NULL     (number of neighbours, kriging estimate, kriging variance) per cell; -1 neighbours =
  *                                       cell was conditioned already
- * num_points in [8, 48] (num_points / 8 per octant).  The kriging systems are solved by Gauss-Jordan elimination on the diagonal
- * (the covariance block is symmetric positive definite) where the reference calls numpy.linalg.lstsq: estimates agree to ~1e-10 relative, not bit for bit.  A cell with no
- * neighbour within `radius` (the reference would widen the search by 100 km, MCMC.py:152-156) returns GSM_E_UNSUPPORTED.
+ *   nbr_trace [dev, total*48] or NULL   the chosen neighbours of every simulated cell (flat index row * W + col, sector by
+ *                                       sector, ascending distance; -1 padded)
+ * num_points in [8, 48] (num_points / 8 per octant; equidistant candidates in ascending (row, col): numpy.argsort(kind='stable')
+ * of the reference's masked array -- the reference's default argsort is unstable, its choice there is implementation-defined).
+ * A cell with no value within `radius` widens the search by 100 km steps like the reference (MCMC.py:150-156).
+ * The kriging systems are solved by Gauss-Jordan elimination on the diagonal (the covariance block is symmetric positive
+ * definite) where the reference calls numpy.linalg.lstsq (_krige.py:37): weights agree to about cond(Sigma) * 1e-16 relative,
+ * not bit for bit.  lstsq(rcond=None) truncates singular values below eps * N * s_max; here a pivot below eps * N * max|diag|
+ * ends the call with GSM_E_DEVICE_DATA ("singular kriging system") instead -- tested range: tests/test_gpu_sgs.py.
+ * Ordinary kriging only: chain_sgs.run never passes ktype (MCMC.py:1599, :160-161), simple kriging (sk_solve) is not built.
  * Synchronises the stream.
  * Replaces: sgs (MCMC.py:91-173), neighbors (gstatsim_custom/neighbors.py:4-64), ok_solve (gstatsim_custom/_krige.py:5-44). */
 int gsm_sgs_blocks(gsm_handle h, double* grids, const double* zcond, const int32_t* windows, const double* x_axis,
-                   const double* y_axis, const double* lag_cov, int32_t hw, double radius, int32_t num_points, double sill,
-                   const int32_t* cell_off, const int32_t* cells, const double* z, double* trace, void* stream);
+                   const double* y_axis, const double* lag_cov, int32_t lag_mi, int32_t lag_mj, int32_t hw, double radius,
+                   int32_t num_points, double sill, const int32_t* cell_off, const int32_t* cells, const double* z,
+                   int32_t max_cells, double* trace, int32_t* nbr_trace, void* stream);
 
 /* gsm_sgs_blocks for batches of iterations: no trace, the chain's cells are cells[cell_off[c] .. cell_off[c] + cell_cnt[c])
  * when cell_cnt is given (else .. cell_off[c + 1]), and NO synchronisation: device-side errors accumulate in the handle and
  * are reported by gsm_sgs_check. */
 int gsm_sgs_blocks_batch(gsm_handle h, double* grids, const double* zcond, const int32_t* windows, const double* x_axis,
-                         const double* y_axis, const double* lag_cov, int32_t hw, double radius, int32_t num_points, double sill,
-                         const int32_t* cell_off, const int32_t* cell_cnt, const int32_t* cells, const double* z, void* stream);
+                         const double* y_axis, const double* lag_cov, int32_t lag_mi, int32_t lag_mj, int32_t hw, double radius,
+                         int32_t num_points, double sill, const int32_t* cell_off, const int32_t* cell_cnt, const int32_t* cells,
+                         const double* z, int32_t max_cells, void* stream);
 /* Synchronises the stream and reports what gsm_sgs_blocks_batch calls since the last check have flagged (GSM_OK if nothing). */
 int gsm_sgs_check(gsm_handle h, void* stream);
 

@@ -34,10 +34,20 @@ class GsmError(RuntimeError):
         self.code = code
 
 
+def _diag_flags() -> list[str]:
+    """Diagnostic defines taken from the environment (scripts/stamps*.py): part of the build's identity."""
+    diag = ["-DGSM_STAMPS"] if os.environ.get("GSM_STAMPS") else []
+    if os.environ.get("GSM_STAMP_TID"):
+        diag.append("-DGSM_STAMP_TID=" + os.environ["GSM_STAMP_TID"])
+    return diag
+
+
 def source_hash() -> str:
-    """First 16 hex digits of the SHA-256 over the library sources (csrc/*.hip, csrc/*.h, include/gsm.h, by name)."""
+    """First 16 hex digits of the SHA-256 over the library sources (csrc/*.hip, csrc/*.h, include/gsm.h, by name) AND the
+    effective compiler flags (a diagnostic build -- GSM_STAMPS -- therefore never passes for the product build)."""
     import hashlib
     h = hashlib.sha256()
+    h.update(repr((HIPCC_FLAGS, sorted(EXTRA_FLAGS.items()), _diag_flags())).encode())
     for p in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")), key=lambda q: q.name) + [HEADER]:
         h.update(p.name.encode())
         h.update(p.read_bytes())
@@ -87,9 +97,7 @@ def _build_locked(force: bool, verbose: bool) -> Path:
         is_version = s == "gsm_version.hip"
         if not force and not is_version and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_t):
             continue
-        diag = ["-DGSM_STAMPS"] if os.environ.get("GSM_STAMPS") else []
-        if os.environ.get("GSM_STAMP_TID"):
-            diag.append("-DGSM_STAMP_TID=" + os.environ["GSM_STAMP_TID"])
+        diag = _diag_flags()
         if is_version:
             diag.append(f'-DGSM_SRC_HASH="{src_hash}"')
         cmd = [hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(s, []), *diag, "-c", "-o", str(obj), str(src)]
@@ -182,10 +190,10 @@ def load() -> C.CDLL:
     lib.gsm_cov_assemble.argtypes = [vp, i32, i32, dbl, C.POINTER(Vario), vp, vp, i64, vp]
     lib.gsm_cholesky_upper.argtypes = [vp, vp, i32, i64, dbl, vp]
     lib.gsm_set_factors.argtypes = [vp, i32, C.POINTER(vp), vp]
-    lib.gsm_sgs_blocks.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, dbl, i32, dbl, vp, vp, vp, vp, vp]
+    lib.gsm_sgs_blocks.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, dbl, i32, dbl, vp, vp, vp, i32, vp, vp, vp]
     lib.gsm_sgs_loss.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.gsm_sgs_commit.argtypes = [vp, vp, vp, vp, vp, vp, vp]
-    lib.gsm_sgs_blocks_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, dbl, i32, dbl, vp, vp, vp, vp, vp]
+    lib.gsm_sgs_blocks_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, dbl, i32, dbl, vp, vp, vp, vp, i32, vp]
     lib.gsm_sgs_check.argtypes = [vp, vp]
     lib.gsm_sgs_draw_philox.argtypes = [vp, vp, i64, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsm_qt_transform.argtypes = [vp, vp, vp, i32, vp, vp, i64, i32, vp]

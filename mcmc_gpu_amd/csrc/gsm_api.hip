@@ -31,6 +31,8 @@ struct gsm_context {
   double* d_k2 = nullptr;        // per-size k^2 tables of the spectral amplitude (depend on rf.resolution)
   double* d_mathtab = nullptr;   // log / sincos table of the coefficient phase (math_tables.h)
   double* d_sgs_part_sum = nullptr; int32_t* d_sgs_part_bad = nullptr; size_t sgs_part_cap = 0;   // gsm_sgs_loss partial sums
+  // gsm_sgs_blocks scratch: visiting ranks + one record per (chain, cell slot), see SgsArgs
+  void* d_sgs_rec = nullptr; size_t sgs_rec_cells = 0;
   int32_t* d_k2_off = nullptr;
   double k2_resolution = 0.0;
   PropScalars* d_scalars[2] = {nullptr, nullptr};
@@ -133,6 +135,7 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_k2) hipFree(h->d_k2);
   if (h->d_mathtab) hipFree(h->d_mathtab);
   if (h->d_sgs_part_sum) { hipFree(h->d_sgs_part_sum); hipFree(h->d_sgs_part_bad); }
+  if (h->d_sgs_rec) hipFree(h->d_sgs_rec);
   if (h->d_k2_off) hipFree(h->d_k2_off);
   if (h->d_factors) hipFree(h->d_factors);
   for (auto& c : h->chol) { if (c.ints) hipFree(c.ints); if (c.zoff) hipFree(c.zoff); if (c.per_rec) hipFree(c.per_rec);
@@ -771,16 +774,38 @@ extern "C" int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* co
 }
 
 static int sgs_fill(gsm_handle h, SgsArgs& a, double* grids, const double* zcond, const int32_t* windows, const double* x_axis,
-                    const double* y_axis, const double* lag_cov, int32_t hw, double radius, int32_t num_points, double sill,
-                    const int32_t* cell_off, const int32_t* cells, const double* z, const char* who) {
+                    const double* y_axis, const double* lag_cov, int32_t lag_mi, int32_t lag_mj, int32_t hw, double radius,
+                    int32_t num_points, double sill, const int32_t* cell_off, const int32_t* cells, const double* z,
+                    int32_t max_cells, const char* who) {
   if (!grids || !windows || !x_axis || !y_axis || !lag_cov || !cell_off || !cells || !z) return fail(h, GSM_E_ARG, std::string(who) + ": NULL pointer");
-  if (hw < 1 || hw > 16) return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": search half-width (radius / grid spacing) must be in [1, 16] cells");
+  if (hw < 1) return fail(h, GSM_E_ARG, std::string(who) + ": search half-width (ceil(radius / grid spacing)) must be >= 1 cell");
   if (num_points < 8 || num_points > 48) return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": num_points must be in [8, 48]");
   if (!(radius > 0.0)) return fail(h, GSM_E_ARG, std::string(who) + ": radius must be > 0");
+  if (lag_mi < 0 || lag_mj < 0) return fail(h, GSM_E_ARG, std::string(who) + ": lag table extents must be >= 0");
+  if (max_cells < 1 || max_cells > 1024) return fail(h, GSM_E_ARG, std::string(who) + ": max_cells must be in [1, 1024]");
+  if (h->H < 2 || h->W < 2 || h->H > 65535 || h->W > 65535) return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": grid sides must be in [2, 65535]");
+  // scratch: ranks [n][1024] i32, rank_ok [n] i32, then per (chain, slot): n i32, var f64, 48 x (idx u32, val f64, w f64)
+  const size_t n = (size_t)h->n_chains, cells_cap = n * (size_t)max_cells;
+  if (h->sgs_rec_cells < cells_cap) {
+    if (h->d_sgs_rec) { hipFree(h->d_sgs_rec); h->d_sgs_rec = nullptr; h->sgs_rec_cells = 0; }
+    const size_t bytes = n * 1024 * 4 + n * 4 + 64 + cells_cap * (8 + 8 + 48 * (8 + 8 + 4));
+    hipError_t e = hipMalloc(&h->d_sgs_rec, bytes);
+    if (e != hipSuccess) return fail(h, GSM_E_HIP, std::string(who) + ": " + hipGetErrorString(e));
+    h->sgs_rec_cells = cells_cap;
+  }
+  char* p = (char*)h->d_sgs_rec;
+  const size_t cap = h->sgs_rec_cells;
+  a.rec_val = (double*)p; p += cap * 48 * 8;
+  a.rec_w = (double*)p; p += cap * 48 * 8;
+  a.rec_var = (double*)p; p += cap * 8;
+  a.rec_idx = (uint32_t*)p; p += cap * 48 * 4;
+  a.rec_n = (int32_t*)p; p += cap * 8;
+  a.rank = (int32_t*)p; p += n * 1024 * 4;
+  a.rank_ok = (int32_t*)p;
   a.H = h->H; a.W = h->W; a.n_chains = h->n_chains;
   a.grid = grids; a.zcond = zcond; a.win = windows; a.xs = x_axis; a.ys = y_axis; a.lag = lag_cov;
-  a.hw = hw; a.m = 2 * hw; a.num_points = num_points; a.radius = radius; a.sill = sill;
-  a.cell_off = cell_off; a.cells = cells; a.z = z; a.err = h->d_err;
+  a.hw = hw; a.mi = lag_mi; a.mj = lag_mj; a.num_points = num_points; a.radius = radius; a.sill = sill;
+  a.cell_off = cell_off; a.cells = cells; a.z = z; a.err = h->d_err; a.max_cells = max_cells;
   return GSM_OK;
 }
 
@@ -792,37 +817,44 @@ static int sgs_report(gsm_handle h, hipStream_t st, const char* who) {
   hipMemsetAsync(h->d_err, 0, sizeof(int32_t), st);
   hipStreamSynchronize(st);
   const std::string w(who);
-  if (flag & 4) return fail(h, GSM_E_UNSUPPORTED, w + ": a cell has no conditioning value within the search radius (the reference's "
-                                                   "radius-widening fallback, MCMC.py:152-156, is not built)");
-  if (flag & 8) return fail(h, GSM_E_DEVICE_DATA, w + ": singular kriging system");
+  if (flag & 4) return fail(h, GSM_E_DEVICE_DATA, w + ": a cell to simulate has no conditioning value anywhere on the grid (the reference "
+                                                   "would widen its search radius for ever, MCMC.py:150-156)");
+  if (flag & 8) return fail(h, GSM_E_DEVICE_DATA, w + ": singular kriging system (a pivot below eps * N * max|diag|: numpy.linalg.lstsq "
+                                                   "would truncate singular values there, _krige.py:37)");
   if (flag & 16) return fail(h, GSM_E_DEVICE_DATA, w + ": no block centre inside the region mask after 64 attempts");
-  return fail(h, GSM_E_DEVICE_DATA, w + ": window outside the grid / larger than 1024 cells (or than max_cells), or a listed cell outside its window");
+  if (flag & 64) return fail(h, GSM_E_ARG, w + ": the lag covariance table does not reach the lag between two chosen neighbours "
+                                            "(lag_mi / lag_mj must cover 2 * hw, or the whole grid when the search radius is widened)");
+  return fail(h, GSM_E_DEVICE_DATA, w + ": window outside the grid / larger than 1024 cells, more cells than max_cells, or a listed cell outside its window");
 }
 
 extern "C" int gsm_sgs_blocks(gsm_handle h, double* grids, const double* zcond, const int32_t* windows, const double* x_axis,
-                              const double* y_axis, const double* lag_cov, int32_t hw, double radius, int32_t num_points, double sill,
-                              const int32_t* cell_off, const int32_t* cells, const double* z, double* trace, void* stream) {
+                              const double* y_axis, const double* lag_cov, int32_t lag_mi, int32_t lag_mj, int32_t hw, double radius,
+                              int32_t num_points, double sill, const int32_t* cell_off, const int32_t* cells, const double* z,
+                              int32_t max_cells, double* trace, int32_t* nbr_trace, void* stream) {
   if (!h) return GSM_E_ARG;
   SgsArgs a{};
-  int rc = sgs_fill(h, a, grids, zcond, windows, x_axis, y_axis, lag_cov, hw, radius, num_points, sill, cell_off, cells, z, "gsm_sgs_blocks");
-  if (rc) return rc;
-  a.cell_cnt = nullptr; a.trace = trace;
-  hipStream_t st = (hipStream_t)stream;
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, launch_sgs_blocks(a, st));
+  int rc = sgs_fill(h, a, grids, zcond, windows, x_axis, y_axis, lag_cov, lag_mi, lag_mj, hw, radius, num_points, sill, cell_off, cells, z,
+                    max_cells, "gsm_sgs_blocks");
+  if (rc) return rc;
+  a.cell_cnt = nullptr; a.trace = trace; a.nbr_trace = nbr_trace;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, launch_sgs_blocks(a, max_cells, st));
   return sgs_report(h, st, "gsm_sgs_blocks");
 }
 
 extern "C" int gsm_sgs_blocks_batch(gsm_handle h, double* grids, const double* zcond, const int32_t* windows, const double* x_axis,
-                                    const double* y_axis, const double* lag_cov, int32_t hw, double radius, int32_t num_points, double sill,
-                                    const int32_t* cell_off, const int32_t* cell_cnt, const int32_t* cells, const double* z, void* stream) {
+                                    const double* y_axis, const double* lag_cov, int32_t lag_mi, int32_t lag_mj, int32_t hw, double radius,
+                                    int32_t num_points, double sill, const int32_t* cell_off, const int32_t* cell_cnt, const int32_t* cells,
+                                    const double* z, int32_t max_cells, void* stream) {
   if (!h) return GSM_E_ARG;
   SgsArgs a{};
-  int rc = sgs_fill(h, a, grids, zcond, windows, x_axis, y_axis, lag_cov, hw, radius, num_points, sill, cell_off, cells, z, "gsm_sgs_blocks_batch");
-  if (rc) return rc;
-  a.cell_cnt = cell_cnt; a.trace = nullptr;
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, launch_sgs_blocks(a, (hipStream_t)stream));
+  int rc = sgs_fill(h, a, grids, zcond, windows, x_axis, y_axis, lag_cov, lag_mi, lag_mj, hw, radius, num_points, sill, cell_off, cells, z,
+                    max_cells, "gsm_sgs_blocks_batch");
+  if (rc) return rc;
+  a.cell_cnt = cell_cnt; a.trace = nullptr; a.nbr_trace = nullptr;
+  HIPCHK(h, launch_sgs_blocks(a, max_cells, (hipStream_t)stream));
   return GSM_OK;
 }
 

@@ -146,17 +146,27 @@ struct SgsArgs {
   const int32_t* win;      // [n_chains*4] r0, r1, c0, c1 of the simulated block
   const double* xs;        // [W] x coordinate of every column
   const double* ys;        // [H] y coordinate of every row
-  const double* lag;       // [(2m+1)^2] covariance at integer lag (di, dj), m = 2 * hw
-  int hw, m, num_points;
+  const double* lag;       // [(2 mi + 1) * (2 mj + 1)] covariance at integer lag (di, dj), |di| <= mi, |dj| <= mj
+  int hw, mi, mj, num_points;
   double radius, sill;
   const int32_t* cell_off; // [n_chains+1] (or [n_chains] with cell_cnt)
   const int32_t* cell_cnt; // optional [n_chains]: number of cells of each chain
   const int32_t* cells;    // [total*2] (i, j) in simulation order
   const double* z;         // [total] standard normals
   double* trace;           // optional [total*3]: (neighbours, estimate, variance)
+  int32_t* nbr_trace;      // optional [total*48]: the chosen neighbours (flat cell index, -1 padded) of every simulated cell
   int32_t* err;
+  // scratch of the handle: visiting ranks of the block cells and one record per (chain, cell slot)
+  int max_cells;           // record stride per chain (>= the largest cell count of the call)
+  int32_t* rank;           // [n_chains][1024]
+  int32_t* rank_ok;        // [n_chains]
+  int32_t* rec_n;          // [n_chains*max_cells] neighbours of the cell; -1: conditioned already; 0: error
+  uint32_t* rec_idx;       // [n_chains*max_cells*48] flat cell index, or 0x80000000 | block-local index of a cell simulated earlier
+  double* rec_val;         // [..*48] the neighbour's value where it is known before the sequence runs
+  double* rec_w;           // [..*48] kriging weights
+  double* rec_var;         // [n_chains*max_cells] |kriging variance|
 };
-hipError_t launch_sgs_blocks(const SgsArgs& a, hipStream_t st);
+hipError_t launch_sgs_blocks(const SgsArgs& a, int launch_cells, hipStream_t st);
 struct SgsDrawArgs {
   int H, W, n_chains, n_iters;
   int64_t iter0;

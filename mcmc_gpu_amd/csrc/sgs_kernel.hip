@@ -1,30 +1,45 @@
 // Small-scale chain on gfx950: sequential Gaussian simulation of one block per chain, and the chain's full-grid loss.
 //
-// Replaces, for a batch of chains (one 64-lane workgroup = one wavefront per chain):
-//   sgs                      gstatsMCMC/MCMC.py:91-173   (cell loop :135-168)
+// Replaces, for a batch of chains:
+//   sgs                      gstatsMCMC/MCMC.py:91-173   (cell loop :135-168, radius widening :150-156)
 //   neighbors (octant search) gstatsMCMC/gstatsim_custom/neighbors.py:4-64
 //   ok_solve                 gstatsMCMC/gstatsim_custom/_krige.py:5-44
 //   chain.loss on the proposed bed + thickness guard  MCMC.py:1781-1795 (loss :1021-1044, Topography.py:592-600)
 //
-// The random numbers are the caller's (replay: NumPy's PCG64 on the host, in the reference's order): the order in which
-// the block's cells are visited (rng.shuffle, MCMC.py:128) and one standard normal per simulated cell
-// (rng.normal(est, sqrt(var)) = est + sqrt(var) * z, MCMC.py:165).
+// The random numbers are the caller's (replay: NumPy's PCG64 on the host, in the reference's order; Philox mode:
+// sgs_draw_kernel): the order in which the block's cells are visited (rng.shuffle, MCMC.py:128) and one standard normal per
+// simulated cell (rng.normal(est, sqrt(var)) = est + sqrt(var) * z, MCMC.py:165).
 //
-// Per cell, in the given order, if the cell is not conditioned yet:
-//   1 octant search: every grid cell within +-hw of the cell that holds a value (everything outside the block does: the
-//     current bed; inside the block the conditioning data and the cells simulated so far) and lies closer than `radius` is
-//     put into one of eight 45-degree sectors, (b pi/4, (b+1) pi/4], b = -4..3, of atan2(y0 - y, x0 - x).  The sector is
-//     decided from the signs and magnitudes of the two coordinate differences -- exactly what numpy.arctan2 gives on the
-//     sector boundaries (multiples of pi/4 are hit only by cells on the axes and diagonals, where arctan2 returns the
-//     boundary value bit for bit; checked on the host).  Per sector the num_points / 8 nearest, ties by window position
-//     (NumPy's masked C order followed by a stable sort; numpy.argsort's default sort is stable below 17 elements).
-//   2 ordinary kriging: (n+1) x (n+1) system [Sigma 1; 1^T 0] w = [rho; 1], covariances from a table indexed by the integer
-//     lag between two cells (the host evaluates the reference's covariance model -- scipy's Bessel K for Matern -- once per
-//     lag), solved in LDS by Gauss-Jordan elimination on the diagonal (positive-definite covariance block) in fp64 (the reference calls numpy.linalg.lstsq,
-//     an SVD solve: same solution for these non-singular systems, different rounding -- the stated tolerance of this path).
-//   3 value = est + sqrt(|var|) * z; the cell becomes conditioning data for the cells after it.
-// Limits: hw <= 16 (search window 33 x 33), num_points <= 48, window (block) cells <= 1024.  A cell without any neighbour
-// inside `radius` would make the reference grow the radius by 100 km (MCMC.py:152-156): not built, reported as an error.
+// What depends on what.  A cell's NEIGHBOUR SET and KRIGING WEIGHTS depend only on where values exist when the cell is
+// visited -- everything outside the block, the block's conditioning data, and the block cells visited before it -- not on the
+// values themselves.  So the simulation of a block is split in two:
+//   sgs_weights_kernel   one wavefront per (chain, cell), all cells of all chains side by side: octant search, ordinary-kriging
+//                        system, weights and kriging variance -> a record per cell (neighbour list with the values that are
+//                        known already, weights, standard deviation);
+//   sgs_sequence_kernel  one wavefront per chain walks the cells in visiting order: est = mean + sum w (v - mean),
+//                        value = est + sd * z, the only sequential part (a 48-term dot product per cell).
+//
+// Octant search (exact for any search radius; the reference's driver uses 48 neighbours within 30 km at 500 m = 60 cells):
+// every cell within +-hw of the cell that holds a value and lies closer than `radius` belongs to one of eight 45-degree
+// sectors, (b pi/4, (b+1) pi/4], b = -4..3, of atan2(y0 - y, x0 - x), decided from the signs and magnitudes of the two
+// coordinate differences -- exactly what numpy.arctan2 gives on the sector boundaries (multiples of pi/4 are hit only by
+// cells on the axes and diagonals, where arctan2 returns the boundary value bit for bit; checked on the host).  Per sector
+// the num_points / 8 nearest are kept, equidistant ones in ascending (row, column) -- numpy.argsort(kind='stable') of the
+// reference's masked C-order array; the reference's default argsort is not stable, so its choice among equidistant
+// candidates is implementation-defined.  The window is scanned in square rings of growing Chebyshev
+// radius R.  After ring R every unscanned cell is at least (R + 1) min(|dx|, |dy|) away, so a sector is complete as soon as it
+// holds num_points / 8 candidates closer than that; a sector whose remaining cells all lie outside the grid / window is
+// exhausted.  The scan stops when every sector is complete or exhausted: with values on most cells that is after 4-6 rings,
+// whatever the radius.  A cell without any value inside `radius` widens the search as the reference does (radius += 100 km,
+// window = ceil(radius / |dx|) cells, MCMC.py:150-156) until the window covers the grid.
+//
+// Ordinary kriging: (n+1) x (n+1) system [Sigma 1; 1^T 0] w = [rho; 1], covariances from a table indexed by the integer lag
+// between two cells (the host evaluates the reference's covariance model -- scipy's Bessel K for Matern -- once per lag),
+// solved by Gauss-Jordan elimination on the diagonal (the covariance block is positive definite, the last pivot is
+// -1' Sigma^-1 1) in fp64 with one row of the augmented matrix per lane, held in registers; the pivot row of a step reaches
+// the other lanes through v_readlane.  The reference calls numpy.linalg.lstsq (SVD): same solution, other rounding -- the
+// stated tolerance of this path.  A pivot below eps * N * max|diag| raises the "singular" flag (lstsq would truncate there).
+// Limits: num_points <= 48, block <= 1024 cells.
 #include "gsm_internal.h"
 #include "device_util.h"
 #include "residual_device.h"
@@ -34,48 +49,12 @@
 
 namespace gsm {
 
-constexpr int kSgsMaxHw = 16;
-constexpr int kSgsMaxCand = (2 * kSgsMaxHw + 1) * (2 * kSgsMaxHw + 1);   // 1089
 constexpr int kSgsMaxPts = 48;
-constexpr int kSgsStride = kSgsMaxPts + 3;                                // row stride of the augmented matrix
 constexpr int kSgsMaxWin = 1024;
-constexpr int kSgsCandPerLane = (kSgsMaxCand + 63) / 64;                  // 18
+constexpr int kSgsListCap = 128;          // candidates kept per sector between prunings (a scan pass appends at most 64)
+constexpr int kSgsCertMax = 128;          // rings with certification counters; beyond, a sector completes by exhaustion only
+constexpr uint32_t kSgsPending = 0x80000000u;   // neighbour record: value not known yet (a block cell visited earlier)
 
-// Wave-wide minima on the DPP network (row steps, two row broadcasts, v_readlane of lane 63): a minimum does not depend on
-// the order of its operands, and ds_bpermute shuffles (__shfl_xor) cost an LDS round trip per level -- with 66 minima per
-// simulated cell (neighbour selection, pivot search) they were two thirds of the kernel's time.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_keep_i32(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xF, false); }
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_keep_f64(double x) {
-  const dev::v2i32 b = __builtin_bit_cast(dev::v2i32, x);
-  dev::v2i32 o;
-  o.x = __builtin_amdgcn_update_dpp(b.x, b.x, CTRL, ROW_MASK, 0xF, false);
-  o.y = __builtin_amdgcn_update_dpp(b.y, b.y, CTRL, ROW_MASK, 0xF, false);
-  return __builtin_bit_cast(double, o);
-}
-__device__ __forceinline__ double wave_min_f64(double v) {
-  v = fmin(v, dpp_keep_f64<0xB1, 0xF>(v));     // quad_perm [1,0,3,2]
-  v = fmin(v, dpp_keep_f64<0x4E, 0xF>(v));     // quad_perm [2,3,0,1]
-  v = fmin(v, dpp_keep_f64<0x141, 0xF>(v));    // row_half_mirror
-  v = fmin(v, dpp_keep_f64<0x140, 0xF>(v));    // row_mirror
-  v = fmin(v, dpp_keep_f64<0x142, 0xA>(v));    // row_bcast:15 into rows 1 and 3
-  v = fmin(v, dpp_keep_f64<0x143, 0xC>(v));    // row_bcast:31 into rows 2 and 3
-  const dev::v2i32 b = __builtin_bit_cast(dev::v2i32, v);
-  dev::v2i32 o;
-  o.x = __builtin_amdgcn_readlane(b.x, 63);
-  o.y = __builtin_amdgcn_readlane(b.y, 63);
-  return __builtin_bit_cast(double, o);
-}
-__device__ __forceinline__ int wave_min_i32(int v) {
-  v = min(v, dpp_keep_i32<0xB1, 0xF>(v));
-  v = min(v, dpp_keep_i32<0x4E, 0xF>(v));
-  v = min(v, dpp_keep_i32<0x141, 0xF>(v));
-  v = min(v, dpp_keep_i32<0x140, 0xF>(v));
-  v = min(v, dpp_keep_i32<0x142, 0xA>(v));
-  v = min(v, dpp_keep_i32<0x143, 0xC>(v));
-  return __builtin_amdgcn_readlane(v, 63);
-}
 __device__ __forceinline__ double wave_sum_f64(double v) { return dev::wave64_sum(v); }     // DPP tree, wave-uniform result
 
 // sector b + 4 in 0..7 of atan2(dy, dx) in (b pi/4, (b+1) pi/4]
@@ -92,202 +71,365 @@ __device__ __forceinline__ int octant(double dy, double dx) {
   return (ay > ax) ? 1 : 0;                                    // (-3pi/4, -pi/2) | (-pi, -3pi/4]
 }
 
-// One 64-lane workgroup per chain; the block's cells are simulated one after the other.  Everything a cell needs is read
-// from LDS: the part of the grid its search windows can reach (block + hw cells on every side, staged once; simulated values
-// are written into it as the loop goes), the lag covariance table, the candidates' values.  `staged` = 0 (a region beyond
-// kSgsRegionMax cells, or a lag table beyond kSgsLagMax): the same code reads the grid / the table from global memory.
-constexpr int kSgsRegionMax = 6144;                       // doubles: e.g. an 8 x 8 block with hw = 16 needs 40 x 40
-constexpr int kSgsLagMax = (4 * kSgsMaxHw + 1) * (4 * kSgsMaxHw + 1);   // 4225
-struct SgsLds {
-  double* cand_d; double* cand_v; int8_t* cand_s; double* A; double* nb_val; int* nb_i; int* nb_j; double* region; double* lag;
-};
-static size_t sgs_lds_bytes() {
-  return sizeof(double) * (2 * (size_t)kSgsMaxCand + (size_t)(kSgsMaxPts + 1) * kSgsStride + kSgsMaxPts + kSgsRegionMax + kSgsLagMax) +
-         sizeof(int) * 2 * kSgsMaxPts + ((kSgsMaxCand + 7) & ~7);
+// ---------------------------------------------------------------------------------------------------------------------
+// sgs_rank_kernel: per chain, the visiting rank of every block cell (-1: the cell holds conditioning data and is never
+// simulated), so that the search of cell k knows which block cells hold a value when k is visited.  One workgroup per chain.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgs_rank_kernel(const SgsArgs a) {
+  const int chain = blockIdx.x, tid = threadIdx.x;
+  const int H = a.H, W = a.W;
+  const int r0 = a.win[4 * chain], r1 = a.win[4 * chain + 1], c0 = a.win[4 * chain + 2], c1 = a.win[4 * chain + 3];
+  const int wh = r1 - r0, ww = c1 - c0;
+  int32_t* rank = a.rank + (size_t)chain * kSgsMaxWin;
+  const int k_lo = a.cell_off[chain], cnt = a.cell_cnt ? a.cell_cnt[chain] : a.cell_off[chain + 1] - k_lo;
+  if (r0 < 0 || c0 < 0 || r1 > H || c1 > W || wh < 0 || ww < 0 || wh * ww > kSgsMaxWin || cnt > a.max_cells || cnt < 0) {
+    if (tid == 0) { atomicOr(a.err, 1); a.rank_ok[chain] = 0; }
+    return;
+  }
+  if (tid == 0) a.rank_ok[chain] = 1;
+  for (int p = tid; p < wh * ww; p += 256) rank[p] = 0x7fffffff;          // a window cell that is not listed never holds a value
+  __syncthreads();
+  const double* g = a.grid + (size_t)chain * H * W;
+  for (int k = tid; k < cnt; k += 256) {
+    const int i = a.cells[2 * (k_lo + k)], j = a.cells[2 * (k_lo + k) + 1];
+    if (i < r0 || i >= r1 || j < c0 || j >= c1) { atomicOr(a.err, 2); continue; }
+    const double v = a.zcond ? a.zcond[i * W + j] : g[i * W + j];
+    rank[(i - r0) * ww + (j - c0)] = isnan(v) ? k : -1;
+  }
 }
 
-__global__ __launch_bounds__(64) void sgs_blocks_kernel(const SgsArgs a) {
-  extern __shared__ double sgs_lds[];
-  SgsLds L;
-  L.cand_d = sgs_lds; L.cand_v = L.cand_d + kSgsMaxCand; L.A = L.cand_v + kSgsMaxCand;
-  L.nb_val = L.A + (kSgsMaxPts + 1) * kSgsStride; L.region = L.nb_val + kSgsMaxPts; L.lag = L.region + kSgsRegionMax;
-  L.nb_i = (int*)(L.lag + kSgsLagMax); L.nb_j = L.nb_i + kSgsMaxPts; L.cand_s = (int8_t*)(L.nb_j + kSgsMaxPts);
-  double* const cand_d = L.cand_d; double* const cand_v = L.cand_v; int8_t* const cand_s = L.cand_s; double* const A = L.A;
-  double* const nb_val = L.nb_val; int* const nb_i = L.nb_i; int* const nb_j = L.nb_j;
+// ---------------------------------------------------------------------------------------------------------------------
+// sgs_weights_kernel: one 64-lane workgroup (one wavefront) per (cell slot, chain)
+// ---------------------------------------------------------------------------------------------------------------------
+struct SgsSearchLds {
+  double list_d[8][kSgsListCap];
+  int32_t list_g[8][kSgsListCap];
+  int32_t len[8];
+  int32_t cum[8];
+  int32_t cert[8][kSgsCertMax];           // candidates of a sector by certification ring
+  int32_t nb_g[kSgsMaxPts];
+  int32_t nb_rc[kSgsMaxPts];            // (row << 16) | col
+  double tmp_d[kSgsMaxPts];
+  int32_t tmp_g[kSgsMaxPts];
+};
+
+// keeps the `keep` smallest (distance, cell) of sector s, in ascending order, at the head of its list; all lanes call it
+__device__ __forceinline__ void sgs_prune_sector(SgsSearchLds& L, int s, int keep, int lane) {
+  const int len = L.len[s];
+  __syncthreads();
+  for (int e = lane; e < len; e += 64) {
+    const double d = L.list_d[s][e];
+    const int g = L.list_g[s][e];
+    int r = 0;
+    for (int q = 0; q < len; ++q) {
+      const double dq = L.list_d[s][q];
+      const int gq = L.list_g[s][q];
+      r += (dq < d || (dq == d && gq < g)) ? 1 : 0;
+    }
+    if (r < keep) { L.tmp_d[r] = d; L.tmp_g[r] = g; }
+  }
+  __syncthreads();
+  const int n = min(len, keep);
+  if (lane < n) { L.list_d[s][lane] = L.tmp_d[lane]; L.list_g[s][lane] = L.tmp_g[lane]; }
+  if (lane == 0) L.len[s] = n;
+  __syncthreads();
+}
+
+template <int K>
+struct GjStep {
+  // one Gauss-Jordan step on pivot K: r[] is this lane's row of [A | b] (columns 0..47 neighbours, 48 the Lagrange column,
+  // 49 the right-hand side)
+  static __device__ __forceinline__ void run(double (&r)[50], int lane, int n, double tol, double tol_l, double& mypiv, bool& singular) {
+    if (K < n || K == 48) {                                      // wave-uniform: rows n..47 do not exist
+      const dev::v2i32 pb = __builtin_bit_cast(dev::v2i32, r[K]);
+      dev::v2i32 ps;
+      ps.x = __builtin_amdgcn_readlane(pb.x, K);
+      ps.y = __builtin_amdgcn_readlane(pb.y, K);
+      const double pv = __builtin_bit_cast(double, ps);
+      if (!(fabs(pv) > (K == 48 ? tol_l : tol))) singular = true;
+      const double rp = 1.0 / pv;
+      double f = dev::exact_div(r[K], pv, rp);
+      if (lane == K) { f = 0.0; mypiv = pv; }
+#pragma unroll
+      for (int j = K + 1; j < 50; ++j) {
+        const dev::v2i32 b = __builtin_bit_cast(dev::v2i32, r[j]);
+        dev::v2i32 o;
+        o.x = __builtin_amdgcn_readlane(b.x, K);
+        o.y = __builtin_amdgcn_readlane(b.y, K);
+        r[j] = __fma_rn(-f, __builtin_bit_cast(double, o), r[j]);
+      }
+    }
+    GjStep<K + 1>::run(r, lane, n, tol, tol_l, mypiv, singular);
+  }
+};
+template <>
+struct GjStep<49> {
+  static __device__ __forceinline__ void run(double (&)[50], int, int, double, double, double&, bool&) {}
+};
+
+__global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
+  __shared__ SgsSearchLds L;
+  const int slot = blockIdx.x, chain = blockIdx.y, lane = threadIdx.x;
+  if (!a.rank_ok[chain]) return;
+  const int k_lo = a.cell_off[chain], cnt = a.cell_cnt ? a.cell_cnt[chain] : a.cell_off[chain + 1] - k_lo;
+  if (slot >= cnt) return;
+  const int H = a.H, W = a.W;
+  const size_t rec = (size_t)chain * a.max_cells + slot;
+  const int i0 = a.cells[2 * (k_lo + slot)], j0 = a.cells[2 * (k_lo + slot) + 1];
+  const int r0 = a.win[4 * chain], r1 = a.win[4 * chain + 1], c0 = a.win[4 * chain + 2], c1 = a.win[4 * chain + 3];
+  const int ww = c1 - c0;
+  if (i0 < r0 || i0 >= r1 || j0 < c0 || j0 >= c1) { if (lane == 0) a.rec_n[rec] = -1; return; }     // flagged by sgs_rank_kernel
+  const int32_t* rank = a.rank + (size_t)chain * kSgsMaxWin;
+  if (rank[(i0 - r0) * ww + (j0 - c0)] != slot) { if (lane == 0) a.rec_n[rec] = -1; return; }       // conditioned already (MCMC.py:141)
+  const double* __restrict__ g = a.grid + (size_t)chain * H * W;
+  const int k8 = a.num_points / 8;
+  const double x0 = a.xs[j0], y0 = a.ys[i0];
+  const double sx = a.xs[1] - a.xs[0], sy = a.ys[1] - a.ys[0];
+  const double adx = fabs(sx), ady = fabs(sy), dmin = fmin(adx, ady);
+  const double inv_cert = 1.0 / (dmin * (1.0 - 1e-6));          // certification ring of a distance: floor(d * inv_cert)
+  const double fac_x = fmin(1.0, ady / adx), fac_y = fmin(1.0, adx / ady);
+  double radius = a.radius;
+  int hw = a.hw;
+  int n = 0;
+  for (;;) {                                                     // radius widening (MCMC.py:150-156): usually one trip
+    const int ilo = max(0, i0 - hw), ihi = min(H - 1, i0 + hw), jlo = max(0, j0 - hw), jhi = min(W - 1, j0 + hw);
+    // cells towards smaller / larger row and column that the window holds
+    const int e_up = i0 - ilo, e_dn = ihi - i0, e_lf = j0 - jlo, e_rt = jhi - j0;
+    const int r_max = max(max(e_up, e_dn), max(e_lf, e_rt));
+    // sector s: extent (in cells) along its primary axis on its side.  dy = y0 - y > 0 <=> rows with smaller y.
+    const int e_ypos = (sy > 0.0) ? e_up : e_dn, e_yneg = (sy > 0.0) ? e_dn : e_up;
+    const int e_xpos = (sx > 0.0) ? e_lf : e_rt, e_xneg = (sx > 0.0) ? e_rt : e_lf;
+    for (int q = lane; q < 8 * kSgsCertMax; q += 64) (&L.cert[0][0])[q] = 0;
+    if (lane < 8) { L.len[lane] = 0; L.cum[lane] = 0; }
+    __syncthreads();
+    int my_ext = 0;
+    double my_fac = 1.0;
+    if (lane < 8) {
+      const bool xprim = (lane == 3 || lane == 4 || lane == 7 || lane == 0);
+      my_fac = xprim ? fac_x : fac_y;
+      my_ext = (lane == 3 || lane == 4) ? e_xpos : (lane == 7 || lane == 0) ? e_xneg : (lane == 5 || lane == 6) ? e_ypos : e_yneg;
+    }
+    unsigned done_mask = 0;                                      // wave-uniform: sectors complete or exhausted
+    int R = 0;
+    while (R < r_max && done_mask != 0xFFu) {
+      // one pass = rings R+1 .. R_hi: the 7 x 7 window first (rings 1-3 = 48 cells), then ring by ring
+      const int R_lo = R + 1, R_hi = (R == 0) ? min(3, r_max) : R + 1;
+      int cells_in_pass, side_w = 0;
+      if (R == 0) { side_w = 2 * R_hi + 1; cells_in_pass = side_w * side_w; } else cells_in_pass = 8 * R_hi;
+      for (int t0 = 0; t0 < cells_in_pass; t0 += 64) {
+        const int t = t0 + lane;
+        int di = 0, dj = 0;
+        bool ok = t < cells_in_pass;
+        if (R == 0) {
+          di = t / side_w - R_hi; dj = t % side_w - R_hi;
+          ok = ok && !(di == 0 && dj == 0);
+        } else {
+          const int side = t / (2 * R_hi), o = t - side * 2 * R_hi;
+          if (side == 0) { di = -R_hi; dj = -R_hi + o; }
+          else if (side == 1) { dj = R_hi; di = -R_hi + o; }
+          else if (side == 2) { di = R_hi; dj = R_hi - o; }
+          else { dj = -R_hi; di = R_hi - o; }
+        }
+        const int i = i0 + di, j = j0 + dj;
+        ok = ok && i >= ilo && i <= ihi && j >= jlo && j <= jhi;
+        if (ok) {
+          bool has;
+          if (i >= r0 && i < r1 && j >= c0 && j < c1) {
+            const int rk = rank[(i - r0) * ww + (j - c0)];
+            has = rk < slot;                                     // -1: conditioning data; < slot: simulated before this cell
+          } else {
+            has = !isnan(g[i * W + j]);
+          }
+          if (has) {
+            const double ddx = x0 - a.xs[j], ddy = y0 - a.ys[i];
+            const double d = sqrt(ddx * ddx + ddy * ddy);
+            if (d < radius) {
+              const int s = octant(ddy, ddx);
+              if (!((done_mask >> s) & 1u)) {
+                const int pos = atomicAdd(&L.len[s], 1);
+                L.list_d[s][pos] = d; L.list_g[s][pos] = i * W + j;
+                const double qf = d * inv_cert;
+                if (qf < (double)kSgsCertMax) atomicAdd(&L.cert[s][(int)qf], 1);
+              }
+            }
+          }
+        }
+        __syncthreads();
+        // a list that could not take another full pass is cut back to the k8 nearest (nothing beyond them can be selected)
+        for (int s = 0; s < 8; ++s)
+          if (L.len[s] > kSgsListCap - 64) sgs_prune_sector(L, s, k8, lane);
+      }
+      R = R_hi;
+      bool fin = false;
+      if (lane < 8) {
+        int c = L.cum[lane];
+        for (int q = R_lo; q <= R && q < kSgsCertMax; ++q) c += L.cert[lane][q];
+        L.cum[lane] = c;
+        fin = c >= k8 || (double)my_ext <= floor((double)R * my_fac + 1e-6);
+      }
+      done_mask |= (unsigned)(__ballot(fin) & 0xFFull);
+      __syncthreads();
+    }
+    // selection: per sector the k8 nearest in ascending (distance, cell); sectors concatenated in angle order
+    for (int s = 0; s < 8; ++s) {
+      const int len = L.len[s];
+      if (len == 0) continue;
+      for (int e = lane; e < len; e += 64) {
+        const double d = L.list_d[s][e];
+        const int gg = L.list_g[s][e];
+        int r = 0;
+        for (int q = 0; q < len; ++q) {
+          const double dq = L.list_d[s][q];
+          const int gq = L.list_g[s][q];
+          r += (dq < d || (dq == d && gq < gg)) ? 1 : 0;
+        }
+        if (r < k8) L.nb_g[n + r] = gg;
+      }
+      n += min(len, k8);
+    }
+    __syncthreads();
+    if (n > 0) break;
+    // nothing within the radius: the reference adds 100 km and rebuilds the stencil (window = ceil(radius / |dx|) cells)
+    if (ilo == 0 && jlo == 0 && ihi == H - 1 && jhi == W - 1 &&
+        radius * radius > ((double)(W - 1) * adx) * ((double)(W - 1) * adx) + ((double)(H - 1) * ady) * ((double)(H - 1) * ady)) break;
+    radius += 100e3;
+    hw = (int)fmin(ceil(radius / adx), 1.0e6);
+  }
+  if (n == 0) {                                                  // no value anywhere on the grid: the reference would loop forever
+    if (lane == 0) { atomicOr(a.err, 4); a.rec_n[rec] = 0; }
+    return;
+  }
+  if (lane < n) { const int gg = L.nb_g[lane]; const int rr = gg / W; L.nb_rc[lane] = (rr << 16) | (gg - rr * W); }
+  __syncthreads();
+  // ---- ordinary kriging system, one row per lane in registers ----------------------------------------------------------
+  const int mi = a.mi, mj = a.mj, lag_w = 2 * mj + 1;
+  const double* __restrict__ lag = a.lag;
+  double r[50];
+  const int my_rc = (lane < n) ? L.nb_rc[lane] : 0;
+  const int my_i = my_rc >> 16, my_j = my_rc & 0xFFFF;
+  bool lag_ok = true;
+#pragma unroll
+  for (int j = 0; j < 48; ++j) {
+    double v = 0.0;
+    if (j < n) {                                                 // wave-uniform
+      if (lane < n) {
+        const int rc = L.nb_rc[j];
+        const int di = my_i - (rc >> 16), dj = my_j - (rc & 0xFFFF);
+        if (abs(di) > mi || abs(dj) > mj) lag_ok = false; else v = lag[(di + mi) * lag_w + dj + mj];
+      } else if (lane == 48) v = 1.0;
+    }
+    r[j] = v;
+  }
+  {
+    double v48 = 0.0, v49 = 0.0;
+    if (lane < n) {
+      const int di = my_i - i0, dj = my_j - j0;
+      v48 = 1.0;
+      if (abs(di) > mi || abs(dj) > mj) lag_ok = false; else v49 = lag[(di + mi) * lag_w + dj + mj];
+    } else if (lane == 48) v49 = 1.0;
+    r[48] = v48; r[49] = v49;
+  }
+  if (__ballot(!lag_ok)) { if (lane == 0) { atomicOr(a.err, 64); a.rec_n[rec] = 0; } return; }
+  const double rho_l = r[49];
+  const double c00 = lag[mi * lag_w + mj];
+  // relative pivot test: eps * N * max|diag| for the covariance pivots (conditional variances), eps * N / max|diag| for the
+  // Lagrange pivot -1' Sigma^-1 1
+  const double tol = 2.220446049250313e-16 * (double)(n + 1) * fabs(c00), tol_l = 2.220446049250313e-16 * (double)(n + 1) / fabs(c00);
+  double mypiv = 1.0;
+  bool singular = false;
+  GjStep<0>::run(r, lane, n, tol, tol_l, mypiv, singular);
+  if (singular) {
+    if (lane == 0) { atomicOr(a.err, 8); a.rec_n[rec] = 0; }
+    return;
+  }
+  const double w_l = (lane < n) ? r[49] / mypiv : 0.0;
+  double var = a.sill - wave_sum_f64(w_l * rho_l);
+  var = fabs(var);
+  // ---- the cell's record ---------------------------------------------------------------------------------------------
+  if (lane < n) {
+    const int gg = L.nb_g[lane];
+    uint32_t idx = (uint32_t)gg;
+    double val = 0.0;
+    if (my_i >= r0 && my_i < r1 && my_j >= c0 && my_j < c1) {
+      const int bl = (my_i - r0) * ww + (my_j - c0);
+      if (rank[bl] >= 0) idx = kSgsPending | (uint32_t)bl;       // simulated earlier in this block: value comes in sequence
+      else val = a.zcond ? a.zcond[gg] : g[gg];
+    } else {
+      val = g[gg];
+    }
+    a.rec_idx[rec * kSgsMaxPts + lane] = idx;
+    a.rec_val[rec * kSgsMaxPts + lane] = val;
+    a.rec_w[rec * kSgsMaxPts + lane] = w_l;
+    if (a.nbr_trace) a.nbr_trace[(size_t)(k_lo + slot) * kSgsMaxPts + lane] = gg;
+  } else if (lane < kSgsMaxPts && a.nbr_trace) {
+    a.nbr_trace[(size_t)(k_lo + slot) * kSgsMaxPts + lane] = -1;
+  }
+  if (lane == 0) { a.rec_n[rec] = n; a.rec_var[rec] = var; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// sgs_sequence_kernel: one wavefront per chain; the block's cells in visiting order
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sgs_sequence_kernel(const SgsArgs a) {
+  __shared__ double overlay[kSgsMaxWin];
   const int chain = blockIdx.x, lane = threadIdx.x;
+  if (!a.rank_ok[chain]) return;
   const int H = a.H, W = a.W;
   double* __restrict__ g = a.grid + (size_t)chain * H * W;
   const int r0 = a.win[4 * chain], r1 = a.win[4 * chain + 1], c0 = a.win[4 * chain + 2], c1 = a.win[4 * chain + 3];
   const int wh = r1 - r0, ww = c1 - c0;
-  if (r0 < 0 || c0 < 0 || r1 > H || c1 > W || wh < 0 || ww < 0 || wh * ww > kSgsMaxWin) {
-    if (lane == 0) atomicOr(a.err, 1);
-    return;
-  }
-  const int hw = a.hw, k8 = a.num_points / 8;
-  const int side = 2 * hw + 1, m = a.m, lag_side = 2 * m + 1;
-  const uint32_t side_magic = 65536u / (uint32_t)side + 1u;      // p / side for p < 1985 (side <= 33) as a multiply
-  // region of the grid the search windows of the block's cells can reach
-  const int ri0 = max(0, r0 - hw), ri1 = min(H, r1 + hw), rj0 = max(0, c0 - hw), rj1 = min(W, c1 + hw);
-  const int rh = ri1 - ri0, rw = rj1 - rj0;
-  const bool staged = rh * rw <= kSgsRegionMax;
-  // block cells: conditioning data (or NaN) now, simulated values as the loop goes; in LDS until the end
-  double* const overlay = staged ? L.region : L.region;         // unstaged: the first wh * ww doubles hold the block only
-  if (staged) {
-    for (int p = lane; p < rh * rw; p += 64) {
-      const int i = ri0 + p / rw, j = rj0 + p % rw;
-      const int gi = i * W + j;
-      const bool in_block = i >= r0 && i < r1 && j >= c0 && j < c1;
-      L.region[p] = (in_block && a.zcond) ? a.zcond[gi] : g[gi];
-    }
-  } else {
-    for (int p = lane; p < wh * ww; p += 64) {
-      const int gi = (r0 + p / ww) * W + c0 + p % ww;
-      overlay[p] = a.zcond ? a.zcond[gi] : g[gi];
-    }
-  }
-  const bool lag_lds = lag_side * lag_side <= kSgsLagMax;
-  if (lag_lds) for (int p = lane; p < lag_side * lag_side; p += 64) L.lag[p] = a.lag[p];
-  const double* __restrict__ lag = lag_lds ? L.lag : a.lag;
-  __syncthreads();
-  auto block_index = [&](int i, int j) { return staged ? (i - ri0) * rw + (j - rj0) : (i - r0) * ww + (j - c0); };
-  auto value_at = [&](int i, int j) -> double {
-    if (staged) return L.region[(i - ri0) * rw + (j - rj0)];
-    if (i >= r0 && i < r1 && j >= c0 && j < c1) return overlay[(i - r0) * ww + (j - c0)];
-    return g[i * W + j];
-  };
-  auto lag_cov = [&](int di, int dj) { return lag[(di + m) * lag_side + dj + m]; };
-  const int k_lo = a.cell_off[chain], k_hi = a.cell_cnt ? k_lo + a.cell_cnt[chain] : a.cell_off[chain + 1];
-  for (int k = k_lo; k < k_hi; ++k) {
-    const int i0 = a.cells[2 * k], j0 = a.cells[2 * k + 1];
-    if (i0 < r0 || i0 >= r1 || j0 < c0 || j0 >= c1) { if (lane == 0) atomicOr(a.err, 2); continue; }
-    const int op = block_index(i0, j0);
-    if (!isnan(overlay[op])) {                       // conditioned already: nothing drawn for it (MCMC.py:141)
-      if (a.trace && lane == 0) { a.trace[3 * k] = -1.0; a.trace[3 * k + 1] = overlay[op]; a.trace[3 * k + 2] = 0.0; }
-      continue;
-    }
-    // ---- 1 candidates of the search window -> (distance, sector) in registers, value in LDS -----------
-    // candidate p = lane + 64 t of the (2 hw + 1)^2 window, t < kSgsCandPerLane: the loops over t are unrolled, so the
-    // two arrays live in registers and the 2 * num_points selection rounds below never touch LDS
-    const double x0 = a.xs[j0], y0 = a.ys[i0];
-    double cd[kSgsCandPerLane];
-    int cs[kSgsCandPerLane];
-#pragma unroll
-    for (int t = 0; t < kSgsCandPerLane; ++t) {
-      const int p = lane + 64 * t;
-      int sec = -1;
-      double d = 0.0;
-      if (p < side * side) {
-        const int io = (int)(((uint32_t)p * side_magic) >> 16);
-        const int i = i0 - hw + io, j = j0 - hw + (p - io * side);
-        double v = 0.0;
-        if (i >= 0 && i < H && j >= 0 && j < W) {
-          v = value_at(i, j);
-          if (!isnan(v)) {
-            const double dx = x0 - a.xs[j], dy = y0 - a.ys[i];
-            d = sqrt(dx * dx + dy * dy);
-            if (d < a.radius) sec = octant(dy, dx);
-          }
-        }
-        cand_v[p] = v;
-      }
-      cd[t] = d; cs[t] = sec;
-    }
-    __syncthreads();
-    // per sector, in ascending (distance, window position): extract up to k8 points
-    int n = 0;
-    for (int s = 0; s < 8; ++s) {
-      double prev_d = -1.0;
-      int prev_p = -1;
-      for (int r = 0; r < k8; ++r) {
-        double best_d = INFINITY;
-        int best_p = 0x7fffffff;
-#pragma unroll
-        for (int t = 0; t < kSgsCandPerLane; ++t) {
-          if (64 * t >= side * side) break;                    // wave-uniform: no candidate in this slot for any lane
-          const int p = lane + 64 * t;
-          const double d = cd[t];
-          const bool open = (cs[t] == s) && !(d < prev_d || (d == prev_d && p <= prev_p));    // not taken in an earlier round
-          if (open && (d < best_d || (d == best_d && p < best_p))) { best_d = d; best_p = p; }
-        }
-        const double wd = wave_min_f64(best_d);
-        if (wd == INFINITY) break;                                          // sector exhausted
-        // the smallest window position among the lanes that hold the minimum: usually one lane (then its position is read
-        // with one v_readlane), else a second reduction
-        const unsigned long long tied = __ballot(best_d == wd);
-        const int wp = (__popcll(tied) == 1) ? __builtin_amdgcn_readlane(best_p, __ffsll((long long)tied) - 1)
-                                             : wave_min_i32((best_d == wd) ? best_p : 0x7fffffff);
-        if (lane == 0) {
-          const int io = (int)(((uint32_t)wp * side_magic) >> 16);
-          nb_i[n] = i0 - hw + io; nb_j[n] = j0 - hw + (wp - io * side); nb_val[n] = cand_v[wp];
-        }
-        prev_d = wd; prev_p = wp;
-        ++n;
-      }
-    }
-    __syncthreads();
-    if (n == 0) {
-      if (lane == 0) { atomicOr(a.err, 4); overlay[op] = NAN; }
-      continue;
-    }
-    // ---- 2 ordinary kriging system, Gauss-Jordan elimination on the diagonal ----------------------------
-    const int N = n + 1;
-    for (int e = lane; e < N * (N + 1); e += 64) {
-      const int ra = e / (N + 1), cb = e % (N + 1);
-      double v;
-      if (cb == N) v = (ra < n) ? lag_cov(nb_i[ra] - i0, nb_j[ra] - j0) : 1.0;      // rho | 1
-      else if (ra < n && cb < n) v = lag_cov(nb_i[ra] - nb_i[cb], nb_j[ra] - nb_j[cb]);
-      else v = (ra == n && cb == n) ? 0.0 : 1.0;
-      A[ra * kSgsStride + cb] = v;
-    }
-    __syncthreads();
-    const double rho_l = (lane < n) ? A[lane * kSgsStride + N] : 0.0;            // kept: the elimination overwrites it
-    bool singular = false;
-    for (int kk = 0; kk < N; ++kk) {
-      // pivot = the diagonal entry: the leading n x n block is a covariance matrix (symmetric positive definite), whose
-      // elimination needs no row exchanges, and the last pivot is -1' Sigma^-1 1 < 0
-      const double pv = A[kk * kSgsStride + kk];
-      if (!(fabs(pv) > 0.0)) { singular = true; break; }
-      // row update: lane = (row slot, column slot) of a 16 x 4 arrangement; a lane takes every fourth column (beyond kk: column
-      // kk itself is not read again) of its rows: a - f * b per entry, f = A[row][kk] / pivot.  One barrier per step.
-      for (int row = lane >> 2; row < N; row += 16) {
-        if (row == kk) continue;
-        const double f = A[row * kSgsStride + kk] / pv;
-        for (int c = kk + 1 + (lane & 3); c <= N; c += 4) A[row * kSgsStride + c] -= f * A[kk * kSgsStride + c];
-      }
-      __syncthreads();
-    }
-    if (singular) {
-      if (lane == 0) { atomicOr(a.err, 8); overlay[op] = NAN; }
-      __syncthreads();
-      continue;
-    }
-    const double w_l = (lane < n) ? A[lane * kSgsStride + N] / A[lane * kSgsStride + lane] : 0.0;
-    const double v_l = (lane < n) ? nb_val[lane] : 0.0;
-    const double local_mean = wave_sum_f64(v_l) / (double)n;
-    const double est = local_mean + wave_sum_f64((lane < n) ? w_l * (v_l - local_mean) : 0.0);
-    double var = a.sill - wave_sum_f64(w_l * rho_l);
-    var = fabs(var);
-    if (lane == 0) {
-      overlay[op] = est + sqrt(var) * a.z[k];
-      if (a.trace) { a.trace[3 * k] = (double)n; a.trace[3 * k + 1] = est; a.trace[3 * k + 2] = var; }
-    }
-    __syncthreads();
-  }
   for (int p = lane; p < wh * ww; p += 64) {
-    const int i = r0 + p / ww, j = c0 + p % ww;
-    g[i * W + j] = overlay[block_index(i, j)];
+    const int gi = (r0 + p / ww) * W + c0 + p % ww;
+    overlay[p] = a.zcond ? a.zcond[gi] : g[gi];
   }
+  __syncthreads();
+  const int k_lo = a.cell_off[chain], cnt = a.cell_cnt ? a.cell_cnt[chain] : a.cell_off[chain + 1] - k_lo;
+  const size_t rec0 = (size_t)chain * a.max_cells;
+  // record of the next cell, requested one cell ahead
+  int n_nx = (cnt > 0) ? a.rec_n[rec0] : -1;
+  uint32_t idx_nx = 0; double val_nx = 0.0, w_nx = 0.0;
+  if (cnt > 0 && lane < kSgsMaxPts) { idx_nx = a.rec_idx[rec0 * kSgsMaxPts + lane]; val_nx = a.rec_val[rec0 * kSgsMaxPts + lane]; w_nx = a.rec_w[rec0 * kSgsMaxPts + lane]; }
+  double var_nx = (cnt > 0) ? a.rec_var[rec0] : 0.0;
+  for (int k = 0; k < cnt; ++k) {
+    const int n = n_nx;
+    const uint32_t idx = idx_nx;
+    const double val = val_nx, w = w_nx, var = var_nx;
+    if (k + 1 < cnt) {
+      const size_t rn = rec0 + k + 1;
+      n_nx = a.rec_n[rn]; var_nx = a.rec_var[rn];
+      if (lane < kSgsMaxPts) { idx_nx = a.rec_idx[rn * kSgsMaxPts + lane]; val_nx = a.rec_val[rn * kSgsMaxPts + lane]; w_nx = a.rec_w[rn * kSgsMaxPts + lane]; }
+    }
+    const int i0 = a.cells[2 * (k_lo + k)], j0 = a.cells[2 * (k_lo + k) + 1];
+    if (i0 < r0 || i0 >= r1 || j0 < c0 || j0 >= c1) continue;            // flagged by sgs_rank_kernel
+    const int op = (i0 - r0) * ww + (j0 - c0);
+    if (n < 0) {                                                          // conditioned already: nothing drawn for it (MCMC.py:141)
+      if (a.trace && lane == 0) { a.trace[3 * (k_lo + k)] = -1.0; a.trace[3 * (k_lo + k) + 1] = overlay[op]; a.trace[3 * (k_lo + k) + 2] = 0.0; }
+      continue;
+    }
+    if (n == 0) {                                                         // error flagged by sgs_weights_kernel
+      if (lane == 0) overlay[op] = NAN;
+      __syncthreads();
+      continue;
+    }
+    const bool act = lane < n;
+    const double v_l = act ? ((idx & kSgsPending) ? overlay[idx & ~kSgsPending] : val) : 0.0;
+    const double w_l = act ? w : 0.0;
+    const double local_mean = wave_sum_f64(v_l) / (double)n;
+    const double est = local_mean + wave_sum_f64(act ? w_l * (v_l - local_mean) : 0.0);
+    if (lane == 0) {
+      overlay[op] = est + sqrt(var) * a.z[k_lo + k];
+      if (a.trace) { a.trace[3 * (k_lo + k)] = (double)n; a.trace[3 * (k_lo + k) + 1] = est; a.trace[3 * (k_lo + k) + 2] = var; }
+    }
+    __syncthreads();
+  }
+  for (int p = lane; p < wh * ww; p += 64) g[(size_t)(r0 + p / ww) * W + c0 + p % ww] = overlay[p];
 }
 
-hipError_t launch_sgs_blocks(const SgsArgs& a, hipStream_t st) {
-  if (a.hw < 1 || a.hw > kSgsMaxHw || a.num_points < 8 || a.num_points > kSgsMaxPts) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)sgs_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(sgs_blocks_kernel, dim3(a.n_chains), dim3(64), sgs_lds_bytes(), st, a);
+hipError_t launch_sgs_blocks(const SgsArgs& a, int launch_cells, hipStream_t st) {
+  if (a.hw < 1 || a.num_points < 8 || a.num_points > kSgsMaxPts || a.H < 2 || a.W < 2 || a.H > 65535 || a.W > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sgs_rank_kernel, dim3(a.n_chains), dim3(256), 0, st, a);
+  if (launch_cells > 0) hipLaunchKernelGGL(sgs_weights_kernel, dim3(launch_cells, a.n_chains), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(sgs_sequence_kernel, dim3(a.n_chains), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 

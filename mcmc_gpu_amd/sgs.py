@@ -62,17 +62,27 @@ def rotation_matrix(v: dict) -> np.ndarray:
                   np.array([[1 / v["major_range"], 0], [0, 1 / v["minor_range"]]]))
 
 
-def lag_cov_table(vario: dict, hw: int, dx: float, dy: float) -> np.ndarray:
-    """Covariance at every integer lag (di, dj), |di|, |dj| <= 2 hw, between two cells of an axis-aligned grid with column
-    spacing dx and row spacing dy (signed): what make_sigma / make_rho (_krige.py:105-143) evaluate pair by pair."""
-    m = 2 * int(hw)
+def lag_cov_table(vario: dict, hw: int, dx: float, dy: float, mi: int | None = None, mj: int | None = None) -> np.ndarray:
+    """Covariance at every integer lag (di, dj), |di| <= mi, |dj| <= mj (default 2 hw: two neighbours of one cell), between
+    two cells of an axis-aligned grid with column spacing dx and row spacing dy (signed): what make_sigma / make_rho
+    (_krige.py:105-143) evaluate pair by pair."""
+    mi = 2 * int(hw) if mi is None else int(mi)
+    mj = 2 * int(hw) if mj is None else int(mj)
     R = rotation_matrix(vario)
-    di = np.arange(-m, m + 1)[:, None] * dy
-    dj = np.arange(-m, m + 1)[None, :] * dx
+    di = np.arange(-mi, mi + 1)[:, None] * dy
+    dj = np.arange(-mj, mj + 1)[None, :] * dx
     m0 = dj * R[0, 0] + di * R[1, 0]
     m1 = dj * R[0, 1] + di * R[1, 1]
     h = np.sqrt(m0 * m0 + m1 * m1)
     return np.ascontiguousarray(cov_norm(h, vario["vtype"], vario["sill"], vario["nugget"], vario.get("s")))
+
+
+def lag_extents(hw: int, H: int, W: int) -> tuple[int, int]:
+    """Extents of the lag table handed to gsm_sgs_blocks: the whole grid while that stays small (4 M lags = 32 MiB), so that
+    the radius-widening fallback (MCMC.py:150-156) finds every lag; else what a search window needs."""
+    if (2 * H - 1) * (2 * W - 1) <= (1 << 22):
+        return H - 1, W - 1
+    return min(2 * int(hw), H - 1), min(2 * int(hw), W - 1)
 
 
 def _axes(xx, yy):
@@ -282,7 +292,9 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                        chain.mc_region_mask, chain.resolution, chain.sigma_mc)
         f64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
         d_xs, d_ys = f64(xs), f64(ys)
-        d_lag = f64(lag_cov_table(vario, hw, dx, dy))
+        lag_mi, lag_mj = lag_extents(hw, H, W)
+        d_lag = f64(lag_cov_table(vario, hw, dx, dy, lag_mi, lag_mj))
+        max_cells = min(1024, max(1, (int(chain.block_max_x) - 1) * (int(chain.block_max_y) - 1)))
         d_zcond = f64(z_cond)
         d_trend = f64(trend) if detrend else None
         bed_c = np.stack([np.asarray(b, dtype=np.float64) - trend if detrend else np.asarray(b, dtype=np.float64) for b in initial_beds])
@@ -334,7 +346,6 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
             d_seeds = torch.as_tensor(np.asarray([int(x) & 0xFFFFFFFFFFFFFFFF for x in philox_seeds], dtype=np.uint64).view(np.int64)).to(dev)
             d_region = torch.as_tensor(np.ascontiguousarray(chain.region_mask == 1, dtype=np.uint8)).to(dev) if chain.update_in_region else None
             d_isdata = torch.as_tensor(np.ascontiguousarray(cond_is_data, dtype=np.uint8)).to(dev)
-            max_cells = min(1024, max(1, (int(chain.block_max_x) - 1) * (int(chain.block_max_y) - 1)))
         it_done = 0
         while philox and it_done < n_iter:
             kb = min(batch, n_iter - it_done)
@@ -354,9 +365,9 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                 for j in range(kb):
                     if dev_qt:
                         qt(cur, nxt, 0)
-                    eng._check(lib.gsm_sgs_blocks_batch(h, _ptr(nxt), _ptr(d_zcond), at(d_win, 4 * n * j), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), hw,
+                    eng._check(lib.gsm_sgs_blocks_batch(h, _ptr(nxt), _ptr(d_zcond), at(d_win, 4 * n * j), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), lag_mi, lag_mj, hw,
                                                         rad, npts, float(vario["sill"]), at(d_off, n * j), at(d_cnt, n * j), _ptr(d_cells), _ptr(d_z),
-                                                        eng._stream()))
+                                                        max_cells, eng._stream()))
                     if dev_qt:
                         qt(nxt, prop, 1)
                     eng._check(lib.gsm_sgs_loss(h, _ptr(prop if dev_qt else nxt), _ptr(d_trend), _ptr(d_loss), _ptr(d_bad), eng._stream()))
@@ -408,9 +419,9 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                 for j in range(kb):
                     if dev_qt:
                         qt(cur, nxt, 0)                       # the whole map to normal scores (MCMC.py:1766)
-                    eng._check(lib.gsm_sgs_blocks_batch(h, _ptr(nxt), _ptr(d_zcond), at(d_win, 4 * n * j), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), hw,
+                    eng._check(lib.gsm_sgs_blocks_batch(h, _ptr(nxt), _ptr(d_zcond), at(d_win, 4 * n * j), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), lag_mi, lag_mj, hw,
                                                         rad, npts, float(vario["sill"]), at(d_off, (n + 1) * j), None, at(d_cells, 2 * bases[j]),
-                                                        at(d_z, bases[j]), eng._stream()))
+                                                        at(d_z, bases[j]), max_cells, eng._stream()))
                     if dev_qt:
                         qt(nxt, prop, 1)                      # ... and back (MCMC.py:1777)
                     eng._check(lib.gsm_sgs_loss(h, _ptr(prop if dev_qt else nxt), _ptr(d_trend), _ptr(d_loss), _ptr(d_bad), eng._stream()))
@@ -467,8 +478,9 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                 # the caller's transformer on the whole map, where the reference calls it (MCMC.py:1766)
                 nxt.copy_(f64(np.stack([nst.transform(bed_c[c].reshape(-1, 1)).reshape(H, W) for c in range(n)])))
             with torch.cuda.device(dev):
-                eng._check(lib.gsm_sgs_blocks(h, _ptr(nxt), _ptr(d_zcond), _ptr(d_win), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), hw,
-                                              rad, npts, float(vario["sill"]), _ptr(d_off), _ptr(d_cells), _ptr(d_z), None, eng._stream()))
+                eng._check(lib.gsm_sgs_blocks(h, _ptr(nxt), _ptr(d_zcond), _ptr(d_win), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), lag_mi, lag_mj, hw,
+                                              rad, npts, float(vario["sill"]), _ptr(d_off), _ptr(d_cells), _ptr(d_z), max_cells, None, None,
+                                              eng._stream()))
             if dev_qt:
                 qt(nxt, prop, 1)
                 loss_next, bad = loss_of(prop)

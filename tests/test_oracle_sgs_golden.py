@@ -82,3 +82,56 @@ def test_octant_search_properties():
     for s_ in np.unique(sector):
         ds = d[sector == s_]
         assert ds.size <= 2 and (np.diff(ds) >= 0).all()
+
+
+# ---- golden F11: the reference driver's own small-scale configuration (oracle/make_fixtures_r3.py) ---------------------------
+import sgs_common as sc  # noqa: E402
+
+F11_CASES = {
+    # tag: (tie-free geometry, trend, transformer, vario_param, sgs_param, sigma, stable sort)
+    "a": (False, True, True, None, None, 5.0, True),
+    "t": (True, True, True, None, None, 5.0, False),
+    "b": (True, False, False, [0, 0.0, 8000.0, 8000.0, 30.0, "Exponential", None], [16, 1200.0, False, 0], 40.0, False),
+    "c": (True, True, False, [35.0, 2.0, 9000.0, 5000.0, 40.0, "Spherical", None], [48, 30e3, False, 0], 40.0, False),
+}
+
+
+def f11_case(tag):
+    """(golden arrays, problem, trend, transformer, vario_param, sgs_param, sigma, stable) of F11 case `tag`."""
+    g = np.load(sc.GOLD11, allow_pickle=False)
+    tie_free, use_trend, use_nst, vp, sp, sigma, stable = F11_CASES[tag]
+    prob = sc.driver_problem(int(g["H"]), dy=float(g["tie_free_dy"]) if tie_free else 500.0)
+    trend, nst = sc.driver_trend_and_transformer(prob)
+    assert hashlib.sha256(np.ascontiguousarray(trend).tobytes()).hexdigest() == str(g["trend_sha"]), "scipy's gaussian_filter differs here"
+    assert hashlib.sha256(np.ascontiguousarray(nst.quantiles_).tobytes()).hexdigest() == str(g["quantiles_sha"]), "sklearn's quantiles differ here"
+    return g, prob, (trend if use_trend else None), (nst if use_nst else None), vp, sp, sigma, stable
+
+
+@pytest.mark.parametrize("tag", ["a", "t", "b", "c"])
+def test_sgs_oracle_reproduces_driver_config_fixture(tag):
+    """F11: 48 neighbours within 30 km at 500 m (search half-width 60 cells), blocks 5-20, Matern, QuantileTransformer(1000),
+    trend (case a: square grid, argsort forced stable in the reference; t: tie-free geometry, unmodified reference), the
+    radius-widening fallback (b) and the spherical far field with 48 neighbours (c)."""
+    g, prob, trend, nst, vp, sp, sigma, stable = f11_case(tag)
+    cfg = sc.driver_cfg(prob, trend, nst, vp, sp, None, sigma)
+    rng = np.random.default_rng(seed=int(g[f"{tag}_seed"]))
+    trace = []
+    so.STABLE_TIES, so.TIE_LOG = stable, []
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = so.run_chain_sgs(cfg, prob["bed"], int(g[f"{tag}_n_iter"]), rng, trace=trace)
+        tied = len(so.TIE_LOG)
+    finally:
+        so.STABLE_TIES, so.TIE_LOG = False, None
+    assert tied == int(g[f"{tag}_tied_cuts"])
+    assert (tied == 0) or stable
+    for k, name in ((0, "bed"), (3, "loss"), (4, "steps"), (5, "resampled"), (6, "blocks")):
+        assert np.array_equal(out[k], g[f"{tag}_{name}"], equal_nan=True), name
+    assert rng.bit_generator.state == json.loads(str(g[f"{tag}_rng_state"]))
+    tr = np.array(trace)
+    assert len(trace) == int(g[f"{tag}_n_sim"])
+    assert hashlib.sha256(np.ascontiguousarray(tr).tobytes()).hexdigest() == str(g[f"{tag}_trace_sha"])
+    if tag == "b":
+        assert tr[:, 2].min() >= 1                         # the widened search found something for every cell
