@@ -300,6 +300,23 @@ int gsm_sgs_loss(gsm_handle h, const double* beds, const double* trend, double* 
 int gsm_sgs_decide(gsm_handle h, const double* loss_next, const int32_t* bad, const double* u, double* loss_prev,
                    uint8_t* accept, double* loss_rec, uint8_t* acc_rec, int64_t rec_stride, void* stream);
 
+/* Windowed end of a small-scale iteration for chains WITHOUT a normal-score transformer.  The reference recomputes residual, loss
+ * and thickness guard over the whole map every iteration (MCMC.py:1781-1795); without a transformer only the block differs from the
+ * current bed, so only the residuals of the block and its one-cell halo change.  Carried per chain: `energy` [dev, n_chains*H*W]
+ * (squared residual where mc_mask == 1 and the residual is not NaN, else 0 -- as the large-scale step kernels carry it) and
+ * state [dev, n_chains*4] = (sum of energy: hi, lo of a compensated pair; loss = sum / (2 sigma^2); number of cells with
+ * update_mask == 1 -- set it to grounded_ice_mask -- and surf - (bed + trend) <= 0).
+ * gsm_sgs_state_init fills both from the current beds (trend [dev, H*W] or NULL).
+ * gsm_sgs_finish: loss and guard of the proposal `next` (== `cur` outside windows[c]) from the halo window, the acceptance test of
+ * gsm_sgs_decide with u[c], then gsm_sgs_commit's bookkeeping (cur / next / resampled) and the update of energy / state of an
+ * accepted chain.  accept [dev, n_chains]; loss_rec / acc_rec / rec_stride as in gsm_sgs_decide.  The loss equals the full-grid
+ * nansum up to summation order (<= 1e-12 relative).  A window whose halo exceeds 36 x 36 cells is reported by gsm_sgs_check.
+ * Replaces: chain_sgs.run's per-iteration loss, guard, acceptance test and commit (MCMC.py:1781-1812) when do_transform is False. */
+int gsm_sgs_state_init(gsm_handle h, const double* beds, const double* trend, double* energy, double* state, void* stream);
+int gsm_sgs_finish(gsm_handle h, double* cur, double* next, const double* trend, double* energy, double* state,
+                   const int32_t* windows, const double* u, uint32_t* resampled, uint8_t* accept, double* loss_rec,
+                   uint8_t* acc_rec, int64_t rec_stride, void* stream);
+
 /* scikit-learn's QuantileTransformer(output_distribution="normal") of one feature on the device, as chain_sgs.run applies it
  * to the whole map around every SGS block (MCMC.py:1766, :1777): out[i] = transform(x[i]) (inverse == 0) or
  * inverse_transform(x[i]) (inverse != 0), i < n.  quantiles = transformer.quantiles_[:, 0], references =

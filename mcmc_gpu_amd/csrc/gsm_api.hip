@@ -784,22 +784,20 @@ static int sgs_fill(gsm_handle h, SgsArgs& a, double* grids, const double* zcond
   if (lag_mi < 0 || lag_mj < 0) return fail(h, GSM_E_ARG, std::string(who) + ": lag table extents must be >= 0");
   if (max_cells < 1 || max_cells > 1024) return fail(h, GSM_E_ARG, std::string(who) + ": max_cells must be in [1, 1024]");
   if (h->H < 2 || h->W < 2 || h->H > 65535 || h->W > 65535) return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": grid sides must be in [2, 65535]");
-  // scratch: ranks [n][1024] i32, rank_ok [n] i32, then per (chain, slot): n i32, var f64, 48 x (idx u32, val f64, w f64)
+  // scratch: per (chain, slot) 48 x (value, weight) and a header; then ranks [n][1024] i32, rank_ok [n] i32
+  max_cells = (max_cells + 31) & ~31;                        // record stride: whole 32-cell chunks (sgs_sequence_kernel stages them by LDS-DMA)
   const size_t n = (size_t)h->n_chains, cells_cap = n * (size_t)max_cells;
   if (h->sgs_rec_cells < cells_cap) {
     if (h->d_sgs_rec) { hipFree(h->d_sgs_rec); h->d_sgs_rec = nullptr; h->sgs_rec_cells = 0; }
-    const size_t bytes = n * 1024 * 4 + n * 4 + 64 + cells_cap * (8 + 8 + 48 * (8 + 8 + 4));
+    const size_t bytes = n * 1024 * 4 + n * 4 + 64 + cells_cap * (sizeof(SgsCellHdr) + 48 * sizeof(double2));
     hipError_t e = hipMalloc(&h->d_sgs_rec, bytes);
     if (e != hipSuccess) return fail(h, GSM_E_HIP, std::string(who) + ": " + hipGetErrorString(e));
     h->sgs_rec_cells = cells_cap;
   }
   char* p = (char*)h->d_sgs_rec;
   const size_t cap = h->sgs_rec_cells;
-  a.rec_val = (double*)p; p += cap * 48 * 8;
-  a.rec_w = (double*)p; p += cap * 48 * 8;
-  a.rec_var = (double*)p; p += cap * 8;
-  a.rec_idx = (uint32_t*)p; p += cap * 48 * 4;
-  a.rec_n = (int32_t*)p; p += cap * 8;
+  a.rec_vw = (double2*)p; p += cap * 48 * sizeof(double2);
+  a.rec_hdr = (SgsCellHdr*)p; p += cap * sizeof(SgsCellHdr);
   a.rank = (int32_t*)p; p += n * 1024 * 4;
   a.rank_ok = (int32_t*)p;
   a.H = h->H; a.W = h->W; a.n_chains = h->n_chains;
@@ -839,7 +837,7 @@ extern "C" int gsm_sgs_blocks(gsm_handle h, double* grids, const double* zcond, 
   if (rc) return rc;
   a.cell_cnt = nullptr; a.trace = trace; a.nbr_trace = nbr_trace;
   hipStream_t st = (hipStream_t)stream;
-  HIPCHK(h, launch_sgs_blocks(a, max_cells, st));
+  HIPCHK(h, launch_sgs_blocks(a, a.max_cells, st));
   return sgs_report(h, st, "gsm_sgs_blocks");
 }
 
@@ -854,7 +852,7 @@ extern "C" int gsm_sgs_blocks_batch(gsm_handle h, double* grids, const double* z
                     max_cells, "gsm_sgs_blocks_batch");
   if (rc) return rc;
   a.cell_cnt = cell_cnt; a.trace = nullptr; a.nbr_trace = nullptr;
-  HIPCHK(h, launch_sgs_blocks(a, max_cells, (hipStream_t)stream));
+  HIPCHK(h, launch_sgs_blocks(a, a.max_cells, (hipStream_t)stream));
   return GSM_OK;
 }
 
@@ -914,6 +912,29 @@ extern "C" int gsm_sgs_decide(gsm_handle h, const double* loss_next, const int32
   if ((loss_rec || acc_rec) && rec_stride < 1) return fail(h, GSM_E_ARG, "gsm_sgs_decide: rec_stride must be >= 1");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, launch_sgs_decide(h->n_chains, loss_next, bad, u, loss_prev, accept, loss_rec, acc_rec, rec_stride, (hipStream_t)stream));
+  return GSM_OK;
+}
+
+extern "C" int gsm_sgs_state_init(gsm_handle h, const double* beds, const double* trend, double* energy, double* state, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_sgs_state_init: call gsm_set_static first");
+  if (h->f32_state) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_state_init: fp64 beds only");
+  if (!beds || !energy || !state) return fail(h, GSM_E_ARG, "gsm_sgs_state_init: NULL pointer");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_sgs_state_init(h->S, h->n_chains, beds, trend, energy, state, (hipStream_t)stream));
+  return GSM_OK;
+}
+
+extern "C" int gsm_sgs_finish(gsm_handle h, double* cur, double* next, const double* trend, double* energy, double* state,
+                              const int32_t* windows, const double* u, uint32_t* resampled, uint8_t* accept, double* loss_rec,
+                              uint8_t* acc_rec, int64_t rec_stride, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_sgs_finish: call gsm_set_static first");
+  if (!cur || !next || !energy || !state || !windows || !u || !resampled || !accept) return fail(h, GSM_E_ARG, "gsm_sgs_finish: NULL pointer");
+  if ((loss_rec || acc_rec) && rec_stride < 1) return fail(h, GSM_E_ARG, "gsm_sgs_finish: rec_stride must be >= 1");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, launch_sgs_finish(h->S, h->n_chains, cur, next, trend, energy, state, windows, u, resampled, accept, loss_rec, acc_rec, rec_stride,
+                              h->d_err, (hipStream_t)stream));
   return GSM_OK;
 }
 

@@ -139,6 +139,13 @@ struct CholArgs {
 };
 
 // small-scale chain: sequential Gaussian simulation of one block per chain (sgs_kernel.hip)
+struct SgsCellHdr {          // one per (chain, cell slot), written by sgs_weights_kernel
+  int32_t n;                 // neighbours; -1: the cell holds conditioning data; -2: cell outside its window; 0: error
+  int32_t op;                // block-local index of the cell
+  double sdz;                // sqrt(|kriging variance|) * the cell's standard normal
+  double var;                // |kriging variance|
+  double c1;                 // (1 - sum of the kriging weights) / n
+};
 struct SgsArgs {
   int H, W, n_chains;
   double* grid;            // [n_chains][H*W] in/out: the conditioning grid; the window's cells are rewritten
@@ -160,11 +167,9 @@ struct SgsArgs {
   int max_cells;           // record stride per chain (>= the largest cell count of the call)
   int32_t* rank;           // [n_chains][1024]
   int32_t* rank_ok;        // [n_chains]
-  int32_t* rec_n;          // [n_chains*max_cells] neighbours of the cell; -1: conditioned already; 0: error
-  uint32_t* rec_idx;       // [n_chains*max_cells*48] flat cell index, or 0x80000000 | block-local index of a cell simulated earlier
-  double* rec_val;         // [..*48] the neighbour's value where it is known before the sequence runs
-  double* rec_w;           // [..*48] kriging weights
-  double* rec_var;         // [n_chains*max_cells] |kriging variance|
+  SgsCellHdr* rec_hdr;     // [n_chains*max_cells]
+  double2* rec_vw;         // [n_chains*max_cells*48] (the neighbour's value, or a NaN-boxed block-local index where the neighbour
+                           //  is a cell simulated earlier in the block; its kriging weight)
 };
 hipError_t launch_sgs_blocks(const SgsArgs& a, int launch_cells, hipStream_t st);
 struct SgsDrawArgs {
@@ -182,6 +187,11 @@ hipError_t launch_sgs_draw(const SgsDrawArgs& a, hipStream_t st);
 int sgs_loss_parts(const StaticFields& S);      // workgroups per chain of the loss kernel; scratch = n_chains * parts doubles + ints
 hipError_t launch_sgs_loss(const StaticFields& S, int n_chains, const double* beds, const double* trend, double* loss, int32_t* bad,
                            double* part_sum, int32_t* part_bad, hipStream_t st);
+hipError_t launch_sgs_state_init(const StaticFields& S, int n_chains, const double* beds, const double* trend, double* energy, double* state,
+                                 hipStream_t st);
+hipError_t launch_sgs_finish(const StaticFields& S, int n_chains, double* cur, double* next, const double* trend, double* energy, double* state,
+                             const int32_t* win, const double* u, uint32_t* resampled, uint8_t* accept, double* loss_rec, uint8_t* acc_rec,
+                             int64_t rec_stride, int32_t* err, hipStream_t st);
 hipError_t launch_sgs_decide(int n_chains, const double* loss_next, const int32_t* bad, const double* u, double* loss_prev,
                              uint8_t* accept, double* loss_rec, uint8_t* acc_rec, int64_t rec_stride, hipStream_t st);
 hipError_t launch_qt(const double* quantiles, const double* references, int nq, double clip_min, double clip_max, const double* x,

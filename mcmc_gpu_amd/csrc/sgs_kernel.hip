@@ -53,9 +53,23 @@ constexpr int kSgsMaxPts = 48;
 constexpr int kSgsMaxWin = 1024;
 constexpr int kSgsListCap = 128;          // candidates kept per sector between prunings (a scan pass appends at most 64)
 constexpr int kSgsCertMax = 128;          // rings with certification counters; beyond, a sector completes by exhaustion only
-constexpr uint32_t kSgsPending = 0x80000000u;   // neighbour record: value not known yet (a block cell visited earlier)
+constexpr uint64_t kSgsPendingTag = 0x7FF8C0DE00000000ull;   // neighbour record: NaN-boxed block-local index of a cell visited earlier
 
 __device__ __forceinline__ double wave_sum_f64(double v) { return dev::wave64_sum(v); }     // DPP tree, wave-uniform result
+// two sums over the 64 lanes at once (independent DPP chains interleave), results wave-uniform
+__device__ __forceinline__ void wave_sum2_f64(double& a, double& b) {
+  a += dev::dpp_f64<0xB1, 0xF>(a);  b += dev::dpp_f64<0xB1, 0xF>(b);
+  a += dev::dpp_f64<0x4E, 0xF>(a);  b += dev::dpp_f64<0x4E, 0xF>(b);
+  a += dev::dpp_f64<0x141, 0xF>(a); b += dev::dpp_f64<0x141, 0xF>(b);
+  a += dev::dpp_f64<0x140, 0xF>(a); b += dev::dpp_f64<0x140, 0xF>(b);
+  a += dev::dpp_f64<0x142, 0xA>(a); b += dev::dpp_f64<0x142, 0xA>(b);
+  a += dev::dpp_f64<0x143, 0xC>(a); b += dev::dpp_f64<0x143, 0xC>(b);
+  const dev::v2i32 ba = __builtin_bit_cast(dev::v2i32, a), bb = __builtin_bit_cast(dev::v2i32, b);
+  dev::v2i32 oa, ob;
+  oa.x = __builtin_amdgcn_readlane(ba.x, 63); oa.y = __builtin_amdgcn_readlane(ba.y, 63);
+  ob.x = __builtin_amdgcn_readlane(bb.x, 63); ob.y = __builtin_amdgcn_readlane(bb.y, 63);
+  a = __builtin_bit_cast(double, oa); b = __builtin_bit_cast(double, ob);
+}
 
 // sector b + 4 in 0..7 of atan2(dy, dx) in (b pi/4, (b+1) pi/4]
 __device__ __forceinline__ int octant(double dy, double dx) {
@@ -147,7 +161,10 @@ struct GjStep {
       ps.y = __builtin_amdgcn_readlane(pb.y, K);
       const double pv = __builtin_bit_cast(double, ps);
       if (!(fabs(pv) > (K == 48 ? tol_l : tol))) singular = true;
-      const double rp = 1.0 / pv;
+      // 1 / pivot: hardware estimate + two Newton steps (every lane computes the same value), then the fma-corrected quotient
+      double rp = __builtin_amdgcn_rcp(pv);
+      rp = __fma_rn(__fma_rn(-pv, rp, 1.0), rp, rp);
+      rp = __fma_rn(__fma_rn(-pv, rp, 1.0), rp, rp);
       double f = dev::exact_div(r[K], pv, rp);
       if (lane == K) { f = 0.0; mypiv = pv; }
 #pragma unroll
@@ -178,9 +195,9 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
   const int i0 = a.cells[2 * (k_lo + slot)], j0 = a.cells[2 * (k_lo + slot) + 1];
   const int r0 = a.win[4 * chain], r1 = a.win[4 * chain + 1], c0 = a.win[4 * chain + 2], c1 = a.win[4 * chain + 3];
   const int ww = c1 - c0;
-  if (i0 < r0 || i0 >= r1 || j0 < c0 || j0 >= c1) { if (lane == 0) a.rec_n[rec] = -1; return; }     // flagged by sgs_rank_kernel
+  if (i0 < r0 || i0 >= r1 || j0 < c0 || j0 >= c1) { if (lane == 0) a.rec_hdr[rec].n = -2; return; }     // flagged by sgs_rank_kernel
   const int32_t* rank = a.rank + (size_t)chain * kSgsMaxWin;
-  if (rank[(i0 - r0) * ww + (j0 - c0)] != slot) { if (lane == 0) a.rec_n[rec] = -1; return; }       // conditioned already (MCMC.py:141)
+  if (rank[(i0 - r0) * ww + (j0 - c0)] != slot) { if (lane == 0) { a.rec_hdr[rec].n = -1; a.rec_hdr[rec].op = (i0 - r0) * ww + (j0 - c0); } return; }       // conditioned already (MCMC.py:141)
   const double* __restrict__ g = a.grid + (size_t)chain * H * W;
   const int k8 = a.num_points / 8;
   const double x0 = a.xs[j0], y0 = a.ys[i0];
@@ -296,7 +313,7 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
     hw = (int)fmin(ceil(radius / adx), 1.0e6);
   }
   if (n == 0) {                                                  // no value anywhere on the grid: the reference would loop forever
-    if (lane == 0) { atomicOr(a.err, 4); a.rec_n[rec] = 0; }
+    if (lane == 0) { atomicOr(a.err, 4); a.rec_hdr[rec].n = 0; a.rec_hdr[rec].op = (i0 - r0) * ww + (j0 - c0); }
     return;
   }
   if (lane < n) { const int gg = L.nb_g[lane]; const int rr = gg / W; L.nb_rc[lane] = (rr << 16) | (gg - rr * W); }
@@ -329,7 +346,7 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
     } else if (lane == 48) v49 = 1.0;
     r[48] = v48; r[49] = v49;
   }
-  if (__ballot(!lag_ok)) { if (lane == 0) { atomicOr(a.err, 64); a.rec_n[rec] = 0; } return; }
+  if (__ballot(!lag_ok)) { if (lane == 0) { atomicOr(a.err, 64); a.rec_hdr[rec].n = 0; a.rec_hdr[rec].op = (i0 - r0) * ww + (j0 - c0); } return; }
   const double rho_l = r[49];
   const double c00 = lag[mi * lag_w + mj];
   // relative pivot test: eps * N * max|diag| for the covariance pivots (conditional variances), eps * N / max|diag| for the
@@ -339,89 +356,112 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
   bool singular = false;
   GjStep<0>::run(r, lane, n, tol, tol_l, mypiv, singular);
   if (singular) {
-    if (lane == 0) { atomicOr(a.err, 8); a.rec_n[rec] = 0; }
+    if (lane == 0) { atomicOr(a.err, 8); a.rec_hdr[rec].n = 0; a.rec_hdr[rec].op = (i0 - r0) * ww + (j0 - c0); }
     return;
   }
   const double w_l = (lane < n) ? r[49] / mypiv : 0.0;
   double var = a.sill - wave_sum_f64(w_l * rho_l);
   var = fabs(var);
+  const double sw = wave_sum_f64(w_l);
   // ---- the cell's record ---------------------------------------------------------------------------------------------
-  if (lane < n) {
-    const int gg = L.nb_g[lane];
-    uint32_t idx = (uint32_t)gg;
-    double val = 0.0;
-    if (my_i >= r0 && my_i < r1 && my_j >= c0 && my_j < c1) {
-      const int bl = (my_i - r0) * ww + (my_j - c0);
-      if (rank[bl] >= 0) idx = kSgsPending | (uint32_t)bl;       // simulated earlier in this block: value comes in sequence
-      else val = a.zcond ? a.zcond[gg] : g[gg];
-    } else {
-      val = g[gg];
+  if (lane < kSgsMaxPts) {
+    double2 vw = make_double2(0.0, 0.0);
+    int gg = -1;
+    if (lane < n) {
+      gg = L.nb_g[lane];
+      vw.y = w_l;
+      if (my_i >= r0 && my_i < r1 && my_j >= c0 && my_j < c1 && rank[(my_i - r0) * ww + (my_j - c0)] >= 0)
+        vw.x = __builtin_bit_cast(double, kSgsPendingTag | (uint64_t)((my_i - r0) * ww + (my_j - c0)));   // simulated earlier in this block
+      else
+        vw.x = (my_i >= r0 && my_i < r1 && my_j >= c0 && my_j < c1 && a.zcond) ? a.zcond[gg] : g[gg];
     }
-    a.rec_idx[rec * kSgsMaxPts + lane] = idx;
-    a.rec_val[rec * kSgsMaxPts + lane] = val;
-    a.rec_w[rec * kSgsMaxPts + lane] = w_l;
+    a.rec_vw[rec * kSgsMaxPts + lane] = vw;
     if (a.nbr_trace) a.nbr_trace[(size_t)(k_lo + slot) * kSgsMaxPts + lane] = gg;
-  } else if (lane < kSgsMaxPts && a.nbr_trace) {
-    a.nbr_trace[(size_t)(k_lo + slot) * kSgsMaxPts + lane] = -1;
   }
-  if (lane == 0) { a.rec_n[rec] = n; a.rec_var[rec] = var; }
+  if (lane == 0) {
+    SgsCellHdr hd;
+    hd.n = n; hd.op = (i0 - r0) * ww + (j0 - c0); hd.sdz = sqrt(var) * a.z[k_lo + slot]; hd.var = var; hd.c1 = (1.0 - sw) / (double)n;
+    a.rec_hdr[rec] = hd;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // sgs_sequence_kernel: one wavefront per chain; the block's cells in visiting order
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSeqChunk = 32;                                   // cells per staged chunk of records
+constexpr int kSeqVwDoubles = kSeqChunk * kSgsMaxPts * 2;       // 3072 = 24 x 128
+constexpr int kSeqHdrDoubles = kSeqChunk * 4;                   // 128
+static_assert(sizeof(SgsCellHdr) == 32 && kSeqVwDoubles % 128 == 0 && kSeqHdrDoubles % 128 == 0, "record chunks are whole 1 KiB pieces");
 __global__ __launch_bounds__(64) void sgs_sequence_kernel(const SgsArgs a) {
   __shared__ double overlay[kSgsMaxWin];
+  __shared__ __attribute__((aligned(16))) double stage[2][kSeqVwDoubles + kSeqHdrDoubles];
   const int chain = blockIdx.x, lane = threadIdx.x;
   if (!a.rank_ok[chain]) return;
   const int H = a.H, W = a.W;
   double* __restrict__ g = a.grid + (size_t)chain * H * W;
   const int r0 = a.win[4 * chain], r1 = a.win[4 * chain + 1], c0 = a.win[4 * chain + 2], c1 = a.win[4 * chain + 3];
   const int wh = r1 - r0, ww = c1 - c0;
+  const int k_lo = a.cell_off[chain], cnt = a.cell_cnt ? a.cell_cnt[chain] : a.cell_off[chain + 1] - k_lo;
+  // The records of a chunk of 32 cells travel global -> LDS by LDS-DMA (no registers, no wait in the cell loop) one chunk
+  // ahead; inside the loop a cell costs two LDS reads, one fused wave reduction and one LDS write.  (Register prefetching two
+  // cells ahead did not work: the compiler rotates the prefetched registers with moves at the loop latch and waits vmcnt(0)
+  // there -- a memory latency per cell, 0.65 us measured.)
+  const double* vw_src = (const double*)(a.rec_vw + (size_t)chain * a.max_cells * kSgsMaxPts);
+  const double* hdr_src = (const double*)(a.rec_hdr + (size_t)chain * a.max_cells);
+  auto request = [&](int chunk) {
+    double* dst = stage[chunk & 1];
+    dma_to_lds<1, 0>(vw_src + (size_t)chunk * kSeqVwDoubles, dst, kSeqVwDoubles, 0, lane);
+    dma_to_lds<1, 0>(hdr_src + (size_t)chunk * kSeqHdrDoubles, dst + kSeqVwDoubles, kSeqHdrDoubles, 0, lane);
+  };
+  if (cnt > 0) request(0);
   for (int p = lane; p < wh * ww; p += 64) {
     const int gi = (r0 + p / ww) * W + c0 + p % ww;
     overlay[p] = a.zcond ? a.zcond[gi] : g[gi];
   }
-  __syncthreads();
-  const int k_lo = a.cell_off[chain], cnt = a.cell_cnt ? a.cell_cnt[chain] : a.cell_off[chain + 1] - k_lo;
-  const size_t rec0 = (size_t)chain * a.max_cells;
-  // record of the next cell, requested one cell ahead
-  int n_nx = (cnt > 0) ? a.rec_n[rec0] : -1;
-  uint32_t idx_nx = 0; double val_nx = 0.0, w_nx = 0.0;
-  if (cnt > 0 && lane < kSgsMaxPts) { idx_nx = a.rec_idx[rec0 * kSgsMaxPts + lane]; val_nx = a.rec_val[rec0 * kSgsMaxPts + lane]; w_nx = a.rec_w[rec0 * kSgsMaxPts + lane]; }
-  double var_nx = (cnt > 0) ? a.rec_var[rec0] : 0.0;
-  for (int k = 0; k < cnt; ++k) {
-    const int n = n_nx;
-    const uint32_t idx = idx_nx;
-    const double val = val_nx, w = w_nx, var = var_nx;
-    if (k + 1 < cnt) {
-      const size_t rn = rec0 + k + 1;
-      n_nx = a.rec_n[rn]; var_nx = a.rec_var[rn];
-      if (lane < kSgsMaxPts) { idx_nx = a.rec_idx[rn * kSgsMaxPts + lane]; val_nx = a.rec_val[rn * kSgsMaxPts + lane]; w_nx = a.rec_w[rn * kSgsMaxPts + lane]; }
+  // one wavefront: its LDS operations execute in order; waiting for the LDS counter orders a write against later reads
+  auto lds_order = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  const int ln = min(lane, kSgsMaxPts - 1);
+  for (int kc = 0; kc < cnt; kc += kSeqChunk) {
+    const int chunk = kc / kSeqChunk;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // this chunk's records (and the overlay's loads) have landed
+    if (kc + kSeqChunk < cnt) request(chunk + 1);                     // the other buffer: its cells were finished a chunk ago
+    const double* st = stage[chunk & 1];
+    const int k_end = min(cnt, kc + kSeqChunk);
+    for (int k = kc; k < k_end; ++k) {
+      const int q = k - kc;
+      const double4 hraw = *(const double4*)(st + kSeqVwDoubles + 4 * q);
+      const double2 v0 = *(const double2*)(st + (q * kSgsMaxPts + ln) * 2);
+      const uint64_t nop = __builtin_bit_cast(uint64_t, hraw.x);
+      const int n = __builtin_amdgcn_readfirstlane((int)(uint32_t)nop), op = __builtin_amdgcn_readfirstlane((int)(nop >> 32));
+      const double sdz = hraw.y, var = hraw.z, c1 = hraw.w;
+      if (n == -2) continue;                                              // cell outside its window: flagged by sgs_rank_kernel
+      if (n < 0) {                                                        // conditioned already: nothing drawn for it (MCMC.py:141)
+        if (a.trace && lane == 0) { a.trace[3 * (k_lo + k)] = -1.0; a.trace[3 * (k_lo + k) + 1] = overlay[op]; a.trace[3 * (k_lo + k) + 2] = 0.0; }
+        continue;
+      }
+      if (n == 0) {                                                       // error flagged by sgs_weights_kernel
+        if (lane == 0) overlay[op] = NAN;
+        lds_order();
+        continue;
+      }
+      const bool act = lane < n;
+      const uint64_t bits = __builtin_bit_cast(uint64_t, v0.x);
+      const bool pending = (bits & 0xFFFFFFFF00000000ull) == kSgsPendingTag;
+      const double v_l = act ? (pending ? overlay[(uint32_t)bits] : v0.x) : 0.0;
+      const double w_l = act ? v0.y : 0.0;
+      // est = mean + sum w (v - mean) (_krige.py:42) as sum w v + sum v * (1 - sum w) / n: the two sums reduce side by side (one
+      // DPP latency instead of two in a row on the chain's critical path), c1 = (1 - sum w) / n comes with the record
+      double sv = v_l, swv = w_l * v_l;
+      wave_sum2_f64(sv, swv);
+      const double est = swv + sv * c1;
+      if (lane == 0) {
+        overlay[op] = est + sdz;
+        if (a.trace) { a.trace[3 * (k_lo + k)] = (double)n; a.trace[3 * (k_lo + k) + 1] = est; a.trace[3 * (k_lo + k) + 2] = var; }
+      }
+      lds_order();
     }
-    const int i0 = a.cells[2 * (k_lo + k)], j0 = a.cells[2 * (k_lo + k) + 1];
-    if (i0 < r0 || i0 >= r1 || j0 < c0 || j0 >= c1) continue;            // flagged by sgs_rank_kernel
-    const int op = (i0 - r0) * ww + (j0 - c0);
-    if (n < 0) {                                                          // conditioned already: nothing drawn for it (MCMC.py:141)
-      if (a.trace && lane == 0) { a.trace[3 * (k_lo + k)] = -1.0; a.trace[3 * (k_lo + k) + 1] = overlay[op]; a.trace[3 * (k_lo + k) + 2] = 0.0; }
-      continue;
-    }
-    if (n == 0) {                                                         // error flagged by sgs_weights_kernel
-      if (lane == 0) overlay[op] = NAN;
-      __syncthreads();
-      continue;
-    }
-    const bool act = lane < n;
-    const double v_l = act ? ((idx & kSgsPending) ? overlay[idx & ~kSgsPending] : val) : 0.0;
-    const double w_l = act ? w : 0.0;
-    const double local_mean = wave_sum_f64(v_l) / (double)n;
-    const double est = local_mean + wave_sum_f64(act ? w_l * (v_l - local_mean) : 0.0);
-    if (lane == 0) {
-      overlay[op] = est + sqrt(var) * a.z[k_lo + k];
-      if (a.trace) { a.trace[3 * (k_lo + k)] = (double)n; a.trace[3 * (k_lo + k) + 1] = est; a.trace[3 * (k_lo + k) + 2] = var; }
-    }
-    __syncthreads();
   }
+  __syncthreads();
   for (int p = lane; p < wh * ww; p += 64) g[(size_t)(r0 + p / ww) * W + c0 + p % ww] = overlay[p];
 }
 
@@ -492,6 +532,150 @@ hipError_t launch_sgs_loss(const StaticFields& S, int n_chains, const double* be
   const int parts = sgs_loss_parts(S);
   hipLaunchKernelGGL(sgs_loss_kernel, dim3(n_chains, parts), dim3(256), 0, st, S, beds, trend, parts, part_sum, part_bad);
   hipLaunchKernelGGL(sgs_loss_finish_kernel, dim3((n_chains + 63) / 64), dim3(64), 0, st, n_chains, parts, S.two_sigma2, part_sum, part_bad, loss, bad);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Windowed iteration end for chains WITHOUT a normal-score transformer (gsm.h: gsm_sgs_state_init / gsm_sgs_finish).  The
+// reference recomputes residual, loss and guard over the whole map every iteration (MCMC.py:1781-1795); without a
+// transformer only the block changes, so only the residuals of the block and its one-cell halo change (5-point stencil).
+// Carried per chain: the plane of squared residuals that enter the loss (`energy`, 0 where mc_mask != 1 or the residual is
+// NaN), their compensated sum, the loss, and the number of grounded cells with non-positive thickness.
+//   state[4 c .. 4 c + 3] = (sum hi, sum lo, loss = sum / (2 sigma^2), bad cells)
+// One 256-thread workgroup per chain: loss / guard of the proposal from the halo window, the acceptance test, the commit.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgs_state_init_kernel(const StaticFields S, const double* beds, const double* trend, double* energy,
+                                                             double* state) {
+  __shared__ double red[8];
+  __shared__ int redb[4];
+  const int chain = blockIdx.x, tid = threadIdx.x;
+  const int plane = S.H * S.W;
+  const double* bed = beds + (size_t)chain * plane;
+  double* en = energy + (size_t)chain * plane;
+  auto bed_at = [&](int rr, int cc) { const int q = rr * S.W + cc; return trend ? bed[q] + trend[q] : bed[q]; };
+  double hi = 0.0, lo = 0.0;
+  int nbad = 0;
+  for (int g = tid; g < plane; g += 256) {
+    const int r = g / S.W, c = g - r * S.W;
+    double e = 0.0;
+    if (S.mc[g] == 1) {
+      const double v = cell_residual(S, r, c, bed_at);
+      if (!isnan(v)) e = v * v;
+    }
+    en[g] = e;
+    double sm, er;
+    dev::two_sum(hi, e, sm, er);
+    hi = sm; lo += er;
+    if (S.upd[g] == 1 && (S.surf[g] - bed_at(r, c)) <= 0.0) ++nbad;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ohi = __shfl_xor(hi, off, 64), olo = __shfl_xor(lo, off, 64);
+    double sm, er;
+    dev::two_sum(hi, ohi, sm, er);
+    hi = sm; lo += olo + er;
+    nbad += __shfl_xor(nbad, off, 64);
+  }
+  if ((tid & 63) == 0) { red[2 * (tid >> 6)] = hi; red[2 * (tid >> 6) + 1] = lo; redb[tid >> 6] = nbad; }
+  __syncthreads();
+  if (tid == 0) {
+    double th = 0.0, tl = 0.0;
+    for (int w = 0; w < 4; ++w) { double sm, er; dev::two_sum(th, red[2 * w], sm, er); th = sm; tl += red[2 * w + 1] + er; }
+    double sm, er;
+    dev::two_sum(th, tl, sm, er);
+    state[4 * chain] = sm; state[4 * chain + 1] = er; state[4 * chain + 2] = (sm + er) / S.two_sigma2;
+    state[4 * chain + 3] = (double)(redb[0] + redb[1] + redb[2] + redb[3]);
+  }
+}
+
+constexpr int kSgsHaloMax = 36 * 36;       // cells of block + halo held in LDS: blocks up to 34 x 34 (or e.g. 16 x 70)
+__global__ __launch_bounds__(256) void sgs_finish_kernel(const StaticFields S, double* cur, double* next, const double* trend, double* energy,
+                                                         double* state, const int32_t* win, const double* u, uint32_t* resampled,
+                                                         uint8_t* accept, double* loss_rec, uint8_t* acc_rec, int64_t rec_stride, int32_t* err) {
+  __shared__ double e_new[kSgsHaloMax];
+  __shared__ double red[8];
+  __shared__ int redb[8];
+  __shared__ int acc_s;
+  const int chain = blockIdx.x, tid = threadIdx.x;
+  const int H = S.H, W = S.W;
+  const size_t base = (size_t)chain * H * W;
+  const int r0 = win[4 * chain], r1 = win[4 * chain + 1], c0 = win[4 * chain + 2], c1 = win[4 * chain + 3];
+  const int hr0 = max(0, r0 - 1), hr1 = min(H, r1 + 1), hc0 = max(0, c0 - 1), hc1 = min(W, c1 + 1);
+  const int hww = hc1 - hc0, hn = (hr1 - hr0) * hww;
+  if (r0 < 0 || c0 < 0 || r1 > H || c1 > W || r1 < r0 || c1 < c0 || hn > kSgsHaloMax) {
+    if (tid == 0) { atomicOr(err, 1); accept[chain] = 0; if (acc_rec) acc_rec[(int64_t)chain * rec_stride] = 0; if (loss_rec) loss_rec[(int64_t)chain * rec_stride] = state[4 * chain + 2]; }
+    return;
+  }
+  const double* nb = next + base;
+  auto next_at = [&](int rr, int cc) { const int q = rr * W + cc; return trend ? nb[q] + trend[q] : nb[q]; };
+  double s_old = 0.0, s_new = 0.0;
+  int bad_old = 0, bad_new = 0;
+  for (int p = tid; p < hn; p += 256) {
+    const int r = hr0 + p / hww, c = hc0 + p % hww, g = r * W + c;
+    double e = 0.0;
+    if (S.mc[g] == 1) {
+      const double v = cell_residual(S, r, c, next_at);
+      if (!isnan(v)) e = v * v;
+    }
+    e_new[p] = e;
+    s_new += e;
+    s_old += energy[base + g];
+    if (r >= r0 && r < r1 && c >= c0 && c < c1 && S.upd[g] == 1) {
+      const double t = trend ? trend[g] : 0.0;
+      bad_new += (S.surf[g] - next_at(r, c)) <= 0.0;
+      bad_old += (S.surf[g] - (trend ? cur[base + g] + t : cur[base + g])) <= 0.0;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s_old += __shfl_xor(s_old, off, 64); s_new += __shfl_xor(s_new, off, 64);
+    bad_old += __shfl_xor(bad_old, off, 64); bad_new += __shfl_xor(bad_new, off, 64);
+  }
+  if ((tid & 63) == 0) { red[2 * (tid >> 6)] = s_old; red[2 * (tid >> 6) + 1] = s_new; redb[2 * (tid >> 6)] = bad_old; redb[2 * (tid >> 6) + 1] = bad_new; }
+  __syncthreads();
+  if (tid == 0) {
+    const double so = ((red[0] + red[2]) + red[4]) + red[6], sn = ((red[1] + red[3]) + red[5]) + red[7];
+    const int bo = redb[0] + redb[2] + redb[4] + redb[6], bn = redb[1] + redb[3] + redb[5] + redb[7];
+    double hi = state[4 * chain], lo = state[4 * chain + 1];
+    double sm, er;
+    dev::two_sum(hi, -so, sm, er); hi = sm; lo += er;
+    dev::two_sum(hi, sn, sm, er); hi = sm; lo += er;
+    dev::two_sum(hi, lo, sm, er); hi = sm; lo = er;
+    const double bad_next = state[4 * chain + 3] - (double)bo + (double)bn;
+    const double lp = state[4 * chain + 2];
+    const double ln = (bad_next > 0.0) ? INFINITY : (hi + lo) / S.two_sigma2;
+    bool acc = true;
+    if (!(lp > ln)) {
+      const double p = exp(lp - ln);
+      acc = u[chain] <= ((p > 1.0) ? 1.0 : p);        // p NaN: the comparison is false (numpy.minimum propagates the NaN)
+    }
+    if (acc) { state[4 * chain] = hi; state[4 * chain + 1] = lo; state[4 * chain + 2] = ln; state[4 * chain + 3] = bad_next; }
+    accept[chain] = acc ? 1 : 0;
+    if (loss_rec) loss_rec[(int64_t)chain * rec_stride] = acc ? ln : lp;
+    if (acc_rec) acc_rec[(int64_t)chain * rec_stride] = acc ? 1 : 0;
+    acc_s = acc ? 1 : 0;
+  }
+  __syncthreads();
+  const bool acc = acc_s != 0;
+  if (acc) for (int p = tid; p < hn; p += 256) energy[base + (size_t)(hr0 + p / hww) * W + hc0 + p % hww] = e_new[p];
+  const int ww = c1 - c0, n = (r1 - r0) * ww;
+  for (int p = tid; p < n; p += 256) {
+    const size_t q = base + (size_t)(r0 + p / ww) * W + c0 + p % ww;
+    if (acc) { cur[q] = next[q]; resampled[q] += 1u; }
+    else next[q] = cur[q];
+  }
+}
+
+hipError_t launch_sgs_state_init(const StaticFields& S, int n_chains, const double* beds, const double* trend, double* energy, double* state,
+                                 hipStream_t st) {
+  hipLaunchKernelGGL(sgs_state_init_kernel, dim3(n_chains), dim3(256), 0, st, S, beds, trend, energy, state);
+  return hipGetLastError();
+}
+hipError_t launch_sgs_finish(const StaticFields& S, int n_chains, double* cur, double* next, const double* trend, double* energy, double* state,
+                             const int32_t* win, const double* u, uint32_t* resampled, uint8_t* accept, double* loss_rec, uint8_t* acc_rec,
+                             int64_t rec_stride, int32_t* err, hipStream_t st) {
+  hipLaunchKernelGGL(sgs_finish_kernel, dim3(n_chains), dim3(256), 0, st, S, cur, next, trend, energy, state, win, u, resampled, accept,
+                     loss_rec, acc_rec, rec_stride, err);
   return hipGetLastError();
 }
 

@@ -315,6 +315,13 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
             return d_loss.cpu().numpy().copy(), d_bad.cpu().numpy().copy()
 
         loss_prev, _ = loss_of(cur)
+        # no transformer: only the block and its one-cell halo change per iteration -> carried squared residuals, windowed loss,
+        # and loss / guard / acceptance test / commit in ONE launch (gsm_sgs_finish); the reference recomputes the whole map
+        windowed = nst is None and os.environ.get('GSM_SGS_WINDOWED', '1') != '0'
+        if windowed:
+            d_energy = torch.empty((n, H, W), dtype=torch.float64, device=dev)
+            d_state = torch.empty((n, 4), dtype=torch.float64, device=dev)
+            eng._check(lib.gsm_sgs_state_init(h, _ptr(cur), _ptr(d_trend), _ptr(d_energy), _ptr(d_state), eng._stream()))
         loss_cache = np.zeros((n, n_iter)); step_cache = np.zeros((n, n_iter)); blocks_cache = np.full((n, n_iter, 4), np.nan)
         loss_cache[:, 0] = loss_prev
         if keep_all:
@@ -368,6 +375,10 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                     eng._check(lib.gsm_sgs_blocks_batch(h, _ptr(nxt), _ptr(d_zcond), at(d_win, 4 * n * j), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), lag_mi, lag_mj, hw,
                                                         rad, npts, float(vario["sill"]), at(d_off, n * j), at(d_cnt, n * j), _ptr(d_cells), _ptr(d_z),
                                                         max_cells, eng._stream()))
+                    if windowed:
+                        eng._check(lib.gsm_sgs_finish(h, _ptr(cur), _ptr(nxt), _ptr(d_trend), _ptr(d_energy), _ptr(d_state), at(d_win, 4 * n * j),
+                                                      at(d_us, n * j), _ptr(resampled), _ptr(d_acc), at(d_lrec, j), at(d_arec, j), kb, eng._stream()))
+                        continue
                     if dev_qt:
                         qt(nxt, prop, 1)
                     eng._check(lib.gsm_sgs_loss(h, _ptr(prop if dev_qt else nxt), _ptr(d_trend), _ptr(d_loss), _ptr(d_bad), eng._stream()))
@@ -422,6 +433,10 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                     eng._check(lib.gsm_sgs_blocks_batch(h, _ptr(nxt), _ptr(d_zcond), at(d_win, 4 * n * j), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), lag_mi, lag_mj, hw,
                                                         rad, npts, float(vario["sill"]), at(d_off, (n + 1) * j), None, at(d_cells, 2 * bases[j]),
                                                         at(d_z, bases[j]), max_cells, eng._stream()))
+                    if windowed:
+                        eng._check(lib.gsm_sgs_finish(h, _ptr(cur), _ptr(nxt), _ptr(d_trend), _ptr(d_energy), _ptr(d_state), at(d_win, 4 * n * j),
+                                                      at(d_us, n * j), _ptr(resampled), _ptr(d_acc), at(d_lrec, j), at(d_arec, j), kb, eng._stream()))
+                        continue
                     if dev_qt:
                         qt(nxt, prop, 1)                      # ... and back (MCMC.py:1777)
                     eng._check(lib.gsm_sgs_loss(h, _ptr(prop if dev_qt else nxt), _ptr(d_trend), _ptr(d_loss), _ptr(d_bad), eng._stream()))

@@ -63,16 +63,21 @@ def template(H, W=None, sigma_mc=5.0, block_range=None, model="Matern", smoothne
     return prob, ch, rf
 
 
-def sgs_template(H, transform=True):
+DRIVER_V1_P = (9932.545836561178, 1.021964658501033, 1.2259010610301213, 0.0)   # T4_SmallScaleChain.ipynb cell 20: range, sill, smoothness, nugget
+
+
+def sgs_template(H, transform=True, light=False):
     """Small-scale chain (chain_sgs_gpu) on the synthetic problem, configured like the reference's small-scale driver
-    (smallScaleChain_multiprocessing.py:470-560): conditioning data along flight-line-like rows / columns, exponential
-    variogram, 16 neighbours, blocks of 3-8 cells, optionally scikit-learn's QuantileTransformer as normal-score transform.
-    Returns (problem dict, chain)."""
+    (smallScaleChain_multiprocessing.py:470-560): radar-like conditioning lines, smooth trend (Gaussian filter of the initial
+    bed, sigma 10 cells), QuantileTransformer(1000) fitted on all of (bed - trend), Matern variogram with the tutorial's
+    fitted parameters, set_sgs_param(48, 30e3) (search half-width 60 cells at 500 m), blocks 5-20, sigma_mc = 5.
+    light=True: the small test configuration of rounds 1-2 (exponential variogram, 16 neighbours within 4 km, blocks 3-8,
+    sigma_mc 60, denser data).  transform=False: no normal-score transform / trend.  Returns (problem dict, chain)."""
     from . import sgs
     prob = synthetic_problem(H)
     data_mask = np.zeros((H, H), dtype=bool)
-    data_mask[::4, :] = True
-    data_mask[:, ::8] = True
+    data_mask[::4 if light else 8, :] = True
+    data_mask[:, ::8 if light else 16] = True
     cond = np.where(data_mask, prob["bed"], np.nan)
     region = np.zeros((H, H), dtype=int)
     region[H // 8: 7 * H // 8, H // 8: 7 * H // 8] = 1
@@ -80,7 +85,7 @@ def sgs_template(H, transform=True):
     ch = sgs.chain_sgs_gpu(prob["xx"], prob["yy"], prob["bed"], prob["surf"], prob["velx"], prob["vely"], prob["dhdt"], prob["smb"],
                            cond, data_mask, np.ones((H, H), dtype=int), prob["resolution"])
     ch.set_update_region(True, region)
-    ch.set_loss_type(sigma_mc=60.0, massConvInRegion=True)
+    ch.set_loss_type(sigma_mc=60.0 if light else 5.0, massConvInRegion=True)
     nst, trend = None, None
     if transform:
         try:                        # as the driver does (:485-493): smooth trend, transformer fitted on all of (bed - trend)
@@ -93,9 +98,14 @@ def sgs_template(H, transform=True):
             nst, trend = None, None
     ch.set_normal_transformation(nst, do_transform=nst is not None)
     ch.set_trend(trend, detrend_map=trend is not None)
-    sill = 1.0 if nst is not None else float(np.var(prob["bed"]))      # normal scores have unit variance
-    ch.set_variogram("Exponential", 6000.0, sill, 0.0, isotropic=True)
-    ch.set_sgs_param(16, 4000.0)
-    ch.set_block_sizes(3, 8, 3, 8)
+    if light:
+        sill = 1.0 if nst is not None else float(np.var(prob["bed"]))      # normal scores have unit variance
+        ch.set_variogram("Exponential", 6000.0, sill, 0.0, isotropic=True)
+        ch.set_sgs_param(16, 4000.0)
+        ch.set_block_sizes(3, 8, 3, 8)
+    else:
+        sill = DRIVER_V1_P[1] if nst is not None else float(np.var(prob["bed"])) * DRIVER_V1_P[1]
+        ch.set_variogram("Matern", DRIVER_V1_P[0], sill, DRIVER_V1_P[3], isotropic=True, vario_smoothness=DRIVER_V1_P[2])
+        ch.set_sgs_param(48, 30e3, sgs_rand_dropout_on=False)
+        ch.set_block_sizes(5, 20, 5, 20)
     return prob, ch
-

@@ -172,8 +172,9 @@ def test_chain_sgs_gpu_equals_oracle_on_more_variograms(vtype, smooth, aniso, np
 
 
 def test_batched_iterations_equal_one_by_one(monkeypatch):
-    """run_many_sgs draws a batch of iterations ahead and decides on the device (gsm_sgs_decide); GSM_SGS_BATCH=1 is the
-    iteration-by-iteration path with the decision on the host.  Same chains, same generators: identical results."""
+    """run_many_sgs draws a batch of iterations ahead and decides on the device (gsm_sgs_finish: windowed loss, no transformer
+    here); GSM_SGS_BATCH=1 is the iteration-by-iteration path with the full-grid loss and the decision on the host.  Same chains,
+    same generators: identical beds, accept masks, counts; losses equal up to summation order."""
     from mcmc_gpu_amd import sgs
     H = 32
     prob = sc.problem(H)
@@ -195,8 +196,9 @@ def test_batched_iterations_equal_one_by_one(monkeypatch):
     (a, sa), (b, sb) = res
     assert sa == sb
     for x, y in zip(a, b):
-        for k in (0, 3, 4, 5, 6):
+        for k in (0, 4, 5, 6):
             assert np.array_equal(x[k], y[k]), k
+        np.testing.assert_allclose(x[3], y[3], rtol=1e-12)
     assert 0.05 < np.mean([x[4].mean() for x in a]) < 0.95
 
 
@@ -292,7 +294,7 @@ def test_small_scale_driver_philox_mode_segments(tmp_path):
     """smallScaleChain_mp(mode='philox'): two 1000-iteration segments (the second resumes from the seed folders' files and
     continues the Philox iteration counter) equal one 2000-iteration call."""
     from mcmc_gpu_amd import driver, sgs, synthetic
-    prob, ch = synthetic.sgs_template(32, transform=False)
+    prob, ch = synthetic.sgs_template(32, transform=False, light=True)
     beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(3)]
     seeds = [811, 822, 833]
     one = driver.smallScaleChain_mp(3, 1, ch, beds, seeds, 5, [2000] * 3, output_path=str(tmp_path / "one"), mode='philox')
@@ -310,7 +312,7 @@ def test_small_scale_driver_starts_its_own_ranks(tmp_path, monkeypatch):
     take contiguous shards of the chains and the results are gathered -- equal to the single-process run in both draw modes."""
     from mcmc_gpu_amd import driver, synthetic
     monkeypatch.setenv("GSM_DIST_BACKEND", "gloo")
-    prob, ch = synthetic.sgs_template(32, transform=False)
+    prob, ch = synthetic.sgs_template(32, transform=False, light=True)
     beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(5)]
     seeds = [911, 922, 933, 944, 955]
     for mode in ("philox", "replay"):
@@ -320,3 +322,32 @@ def test_small_scale_driver_starts_its_own_ranks(tmp_path, monkeypatch):
         for a, b in zip(one, two):
             for x, y in zip(a, b):
                 assert np.array_equal(np.asarray(x, dtype=float), np.asarray(y, dtype=float), equal_nan=True)
+
+
+def test_windowed_iteration_end_equals_the_full_grid_path(monkeypatch):
+    """Without a transformer gsm_sgs_finish scores a proposal from the block and its one-cell halo (carried squared residuals)
+    and decides / commits in the same launch; GSM_SGS_WINDOWED=0 is the full-grid loss + guard + decide + commit sequence that
+    follows the reference's whole-map recomputation (MCMC.py:1781-1812).  Same accept masks, beds and counts; losses equal up to
+    summation order.  With and without a trend; a block at the grid border; a proposal that grounds the ice is refused."""
+    from mcmc_gpu_amd import sgs, synthetic
+    for use_trend in (False, True):
+        res = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("GSM_SGS_WINDOWED", flag)
+            prob, ch = synthetic.sgs_template(48, transform=False, light=True)
+            ch.set_update_region(False)
+            ch.set_loss_type(sigma_mc=60.0, massConvInRegion=False)
+            if use_trend:
+                ch.set_trend(prob["surf"] - 1000.0, detrend_map=True)
+            beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(6)]
+            surf = prob["surf"].copy()
+            surf[20:28, 20:28] = np.max(beds, axis=0)[20:28, 20:28] + 1.5     # thin ice: proposals there often ground it (guard)
+            ch.surf = surf
+            out, _ = sgs.run_many_sgs(ch, beds, [np.random.default_rng(i) for i in range(6)], 400, philox_seeds=[300 + i for i in range(6)])
+            res.append(out)
+        for a, b in zip(*res):
+            assert np.array_equal(a[4], b[4]) and np.array_equal(a[6], b[6]) and np.array_equal(a[5], b[5])
+            assert np.array_equal(a[0], b[0])
+            np.testing.assert_allclose(a[3], b[3], rtol=1e-12)
+        acc = np.mean([o[4].mean() for o in res[0]])
+        assert 0.05 < acc < 0.95
