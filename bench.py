@@ -402,7 +402,7 @@ def main():
             out["cpu_baseline"] = cpu_res
     if world == 1 and default_workload and not args.no_extras:
         extras = {}
-        for name, kw in (("configs[3]", dict(H=512, n_local=1024, generator="cholesky", state="f64", inner=128, batch=32, steps=3, warmup=1)),
+        for name, kw in (("configs[3]", dict(H=512, n_local=1024, generator="cholesky", state="f64", inner=128, batch=64, steps=3, warmup=1)),
                          ("configs[4] one GPU's shard", dict(H=1024, n_local=512, generator="spectral", state="f32", inner=512, batch=32, steps=3, warmup=1))):
             t0 = time.perf_counter()
             try:

@@ -21,8 +21,12 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-Wno-unused-value", "-Wno-unused-result"]
 # per-file extras.  step_flux_kernel: without machine LICM the fp64 polynomial constants of exp() are materialised at
 # their use instead of being hoisted out of the step loop into ~30 VGPRs that are then spilled.
+# cholesky_kernel: keep the MFMA accumulators in VGPRs -- with 256-thread workgroups LLVM otherwise puts them in AGPRs and
+# copies all 32 of them VGPR -> AGPR -> VGPR around the 16 MFMAs of EVERY K step of cz_gemm_kernel (64 v_accvgpr moves and
+# a pipeline drain per step: 12.0 -> 9.x ms per 32768 proposals, scripts/kbench.py).
 EXTRA_FLAGS = {"step_flux_kernel.hip": ["-mllvm", "-disable-machine-licm"],
-               "chain_fused_kernel.hip": ["-mllvm", "-disable-machine-licm"]}
+               "chain_fused_kernel.hip": ["-mllvm", "-disable-machine-licm"],
+               "cholesky_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 OBJ_DIR = PKG_DIR / "_build"
 
 

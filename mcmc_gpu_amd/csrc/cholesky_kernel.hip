@@ -9,21 +9,24 @@
 //                           -> _krige.make_sigma.  Matern takes its values from a host lag table (scipy.special.kv,
 //                           as covariance.py:17-22 does); the closed-form models are evaluated here.
 //   chol_*_kernel           U = chol(Sigma + jitter I)^T, once per (block size, range class): setup, not hot path.
-//   cz_group_* / cz_zgen    bucket the proposals of a launch by (size, range class); draw z ~ N(0, I) (Philox).
-//   cz_gemm_kernel          F^T[p][n] = sum_{k <= n} Z[k][p] U[k][n] on the fp64 matrix cores
-//                           (v_mfma_f64_16x16x4_f64, 64x64 block tiles staged through LDS, triangular K range),
-//                           epilogue: * scale * edge mask -> the field layout the step kernel consumes.
+//   cz_scalars / cz_bucket / cz_zgen   per-proposal scalars; bucket the proposals of a launch by (size, range class) in one
+//                           workgroup (LDS counters); draw z ~ N(0, I) (Philox, table-driven Box-Muller).
+//   cz_gemm_dma_kernel      F^T[p][n] = sum_{k <= n} Z[k][p] U[k][n] on the fp64 matrix cores
+//                           (v_mfma_f64_16x16x4_f64, 64 x 128 block tiles, operands global -> LDS by LDS-DMA, triangular
+//                           K range), epilogue: * scale * edge mask -> the field layout the step kernel consumes.
 //
 // Algorithmic flops per proposal: N^2 (N = bh*bw; N^2/2 multiply-adds), SURVEY.md section 8d.
 
 #include "gsm_internal.h"
 #include "philox.h"
+#include "proposal_device.h"
 #include <math.h>
 
 namespace gsm {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
-constexpr int kTS = 80;   // LDS row stride in doubles (== 16 mod 32: conflict-free fragment reads)
+constexpr int kTS = 80;    // LDS row stride in doubles of a 64-wide tile (== 16 mod 32: conflict-free fragment reads)
+constexpr int kTS2 = 144;  // ... of the 128-wide U tile
 
 // ---------------------------------------------------------------------------------------------------
 // covariance assembly
@@ -107,7 +110,6 @@ __global__ __launch_bounds__(256) void cz_scalars_kernel(const ProposeArgs a, co
   c.scale[rec] = scale;
   const int g = si * c.n_classes + rc;
   c.group_of[rec] = g;
-  atomicAdd(&c.counts[g], 1);
   if (a.rf_scalars) {
     a.rf_scalars[4 * rec] = scale;
     a.rf_scalars[4 * rec + 1] = 0.0;
@@ -116,47 +118,64 @@ __global__ __launch_bounds__(256) void cz_scalars_kernel(const ProposeArgs a, co
   }
 }
 
-// one thread: exclusive scans of the per-group proposal counts (records, padded columns, 64-wide tiles)
-__global__ void cz_scan_kernel(const ProposeArgs a, const CholArgs c) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int rec_off = 0, tile_off = 0, work_off = 0;
-  int64_t z_off = 0;
-  for (int g = 0; g < c.n_groups; ++g) {
-    const int cnt = c.counts[g];
-    const int ppad = (cnt + 63) & ~63;
-    const int si = g / c.n_classes;
-    const int N = a.B.bh[si] * a.B.bw[si];
-    c.rec_off[g] = rec_off;
-    c.tile_off[g] = tile_off;
-    c.z_off[g] = z_off;
-    c.cursor[g] = 0;
-    c.work_off[g] = work_off;
-    rec_off += cnt;
-    tile_off += ppad >> 6;
-    work_off += (ppad >> 6) * ((N + 63) >> 6);            // 64 x 64 output tiles of this group
-    z_off += (int64_t)((N + 63) & ~63) * ppad;
+// Bucketing of a launch's proposals by group (block size, range class), ONE 1024-thread workgroup: counts and cursors live in
+// LDS (one global atomic per record on ~50 counters serialised per address: 0.27 + 0.16 ms per 32768 records), the exclusive
+// scans of the counts (records, padded columns, 64-wide tiles) by thread 0 in between.  The order of a group's records is
+// whatever the LDS atomics make it: a record's field depends on its own (seed, step) only, not on its column.
+__global__ __launch_bounds__(1024) void cz_bucket_kernel(const ProposeArgs a, const CholArgs c) {
+  extern __shared__ int bk[];                     // [n_groups] counts, [n_groups] cursors
+  int* cnt = bk;
+  int* cur = bk + c.n_groups;
+  const int tid = threadIdx.x;
+  const int64_t nrec = (int64_t)a.n_chains * a.n_steps;
+  for (int g = tid; g < c.n_groups; g += 1024) cnt[g] = 0;
+  __syncthreads();
+  for (int64_t rec = tid; rec < nrec; rec += 1024) atomicAdd(&cnt[c.group_of[rec]], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int rec_off = 0, tile_off = 0, work_off = 0;
+    int64_t z_off = 0;
+    for (int g = 0; g < c.n_groups; ++g) {
+      const int n = cnt[g];
+      const int ppad = (n + 63) & ~63;
+      const int si = g / c.n_classes;
+      const int N = a.B.bh[si] * a.B.bw[si];
+      c.counts[g] = n;
+      c.rec_off[g] = rec_off;
+      c.tile_off[g] = tile_off;
+      c.z_off[g] = z_off;
+      c.work_off[g] = work_off;
+      cur[g] = rec_off;
+      rec_off += n;
+      tile_off += ppad >> 6;
+      work_off += (ppad >> 6) * ((N + 127) >> 7);           // 64 x 128 output tiles of this group
+      z_off += (int64_t)((N + 63) & ~63) * ppad;
+    }
+    c.rec_off[c.n_groups] = rec_off;
+    c.tile_off[c.n_groups] = tile_off;
+    c.work_off[c.n_groups] = work_off;
   }
-  c.rec_off[c.n_groups] = rec_off;
-  c.tile_off[c.n_groups] = tile_off;
-  c.work_off[c.n_groups] = work_off;
+  __syncthreads();
+  for (int64_t rec = tid; rec < nrec; rec += 1024) c.order[atomicAdd(&cur[c.group_of[rec]], 1)] = (int)rec;
 }
 
-__global__ __launch_bounds__(256) void cz_scatter_kernel(const ProposeArgs a, const CholArgs c) {
-  const int64_t rec = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (rec >= (int64_t)a.n_chains * a.n_steps) return;
-  const int g = c.group_of[rec];
-  const int pos = atomicAdd(&c.cursor[g], 1);
-  c.order[c.rec_off[g] + pos] = (int)rec;
-}
-
+// the group whose [off[g], off[g + 1]) holds `tile` (off ascending, off[0] = 0): binary search, ~log2(n_groups) dependent loads
 __device__ __forceinline__ int find_group(const int* __restrict__ tile_off, int n_groups, int tile) {
-  int g = 0;
-  while (g + 1 < n_groups && tile_off[g + 1] <= tile) ++g;
-  return g;
+  int lo = 0, hi = n_groups - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_off[mid] <= tile) lo = mid; else hi = mid - 1;
+  }
+  return lo;
 }
 
-// Z[k][p] ~ N(0,1): counter (chain seed, absolute step, stream kStreamCholesky, k >> 1); zero in the padding
+// Z[k][p] ~ N(0,1): counter (chain seed, absolute step, stream kStreamCholesky, k >> 1); zero in the padding.  Box-Muller with
+// the table-driven log / sincos and the lean sqrt of the spectral generator (normals2, proposal_device.h; pinned against NumPy
+// on the same counters to 5e-15, tests/test_gpu_philox.py): half the time of libm's log / sincospi.
 __global__ __launch_bounds__(256) void cz_zgen_kernel(const ProposeArgs a, const CholArgs c) {
+  __shared__ double mt[kMathTabDoubles];
+  for (int i = threadIdx.x; i < kMathTabDoubles; i += 256) mt[i] = a.mathtab[i];
+  __syncthreads();
   const int tile = blockIdx.x;
   if (tile >= c.tile_off[c.n_groups]) return;
   const int g = find_group(c.tile_off, c.n_groups, tile);
@@ -180,13 +199,8 @@ __global__ __launch_bounds__(256) void cz_zgen_kernel(const ProposeArgs a, const
   for (int kp = blockIdx.y * 4 + (threadIdx.x >> 6); kp < Npad / 2; kp += gridDim.y * 4) {
     double z0 = 0.0, z1 = 0.0;
     if (live && 2 * kp < N) {
-      const u32x4 r = philox_draw(seed, step, kStreamCholesky, (uint32_t)kp);
-      const double u1 = u01_open0_from(r.x, r.y), u2 = u01_from(r.z, r.w);
-      const double rad = sqrt(-2.0 * log(u1));
-      double sn, cs;
-      sincospi(2.0 * u2, &sn, &cs);
-      z0 = rad * cs;
-      z1 = (2 * kp + 1 < N) ? rad * sn : 0.0;
+      normals2_key(seed, step, kStreamCholesky, (uint32_t)kp, z0, z1, mt);
+      if (2 * kp + 1 >= N) z1 = 0.0;
     }
     Z[(int64_t)(2 * kp) * ppad + p] = z0;
     Z[(int64_t)(2 * kp + 1) * ppad + p] = z1;
@@ -194,16 +208,18 @@ __global__ __launch_bounds__(256) void cz_zgen_kernel(const ProposeArgs a, const
 }
 
 // ---------------------------------------------------------------------------------------------------
-// F^T = Z^T U  (block tile 64 proposals x 64 cells, 4 waves of 32x32, K step 16, LDS double buffer)
-// ---------------------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(256) void cz_gemm_kernel(const ProposeArgs a, const CholArgs c) {
-  __shared__ double As[2][16][kTS];
-  __shared__ double Bs[2][16][kTS];
-  // Output tiles are enumerated group by group ((block size, range class): one factor U, one Z), n-tile major inside a
-  // group: the workgroups in flight at any time then share one factor (<= 164 MB of its upper half) and one Z (<= 36 MB),
-  // which the Infinity Cache holds -- with a (p-tile, n-tile) grid over all groups every n-tile pass re-read every group's
-  // Z from HBM.
+// F^T = Z^T U on 64 (proposals) x 128 (cells) block tiles: four waves of 32 x 64 (eight accumulator tiles each; per K = 4 six
+// fragment reads feed eight MFMAs), K step 16, two LDS stages, triangular K range (U[k][n] = 0 for k > n).
+// The operand tiles travel global -> LDS by LDS-DMA (global_load_lds, 16 bytes per lane): no VGPR staging and no ds_write --
+// the VGPR -> LDS store path costs ~13 LDS cycles per ds_write_b128 (MI355X_MICROARCH.md, LDS) and a register-staged loop
+// lost 11 % of its time to it (ablation).  An LDS-DMA instruction fills 1 KiB of
+// CONTIGUOUS LDS, lane l bytes [16 l, 16 l + 16), from any 16 global bytes the lane names: the padded row layout (row stride
+// 80 / 144 doubles == 16 mod 32: conflict-free fragment reads) is kept by letting every lane fetch the element pair that
+// belongs at its LDS position; the lanes that land on padding re-fetch a valid pair.  28 chunks per stage, 7 per wave.
+__global__ __launch_bounds__(256) void cz_gemm_dma_kernel(const ProposeArgs a, const CholArgs c) {
+  constexpr int kStageA = 16 * kTS, kStageB = 16 * kTS2, kStage = kStageA + kStageB;     // 1280 + 2304 doubles = 10 + 18 chunks
+  static_assert(kStageA % 128 == 0 && kStageB % 128 == 0, "whole 1 KiB chunks");
+  __shared__ __attribute__((aligned(16))) double stage[2][kStage];
   const int work = blockIdx.x;
   if (work >= c.work_off[c.n_groups]) return;
   const int g = find_group(c.work_off, c.n_groups, work);
@@ -214,47 +230,73 @@ __global__ __launch_bounds__(256) void cz_gemm_kernel(const ProposeArgs a, const
   const int Npad = (N + 63) & ~63;
   const int n_pt = ppad >> 6;
   const int idx = work - c.work_off[g];
-  const int n0 = (idx / n_pt) * 64;
+  const int n0 = (idx / n_pt) * 128;
   const int p0 = (idx % n_pt) * 64;
   const double* __restrict__ Z = c.zbuf + c.z_off[g];        // [Npad][ppad]
   const double* __restrict__ U = c.factors[g];               // [Npad][Npad] upper triangular (= L^T), zero padded
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int wp = (wave & 1) * 32, wn = (wave >> 1) * 32;     // this wave's 32x32 sub-tile
-  const int lr = tid >> 4, lc = (tid & 15) * 4;              // staging: row 0..15, 4 doubles at column lc
+  const int wp = (wave & 1) * 32, wn = (wave >> 1) * 64;     // this wave's 32 x 64 sub-tile
+  const bool right = n0 + 64 < Npad;                          // the tile's right half exists (else its columns are never stored)
 
-  v4f64 acc[2][2];
+  // this lane's source of each of the wave's 7 chunks at k0 = 0, and the chunks' LDS offsets
+  const double* src[7];
+  int64_t step[7];
+  int dst[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int ch = wave + 4 * i;                               // 0..9: Z tile, 10..27: U tile
+    if (ch < 10) {
+      const int u = ch * 64 + lane, row = u / 40, cp = u - row * 40;
+      src[i] = Z + (int64_t)row * ppad + p0 + 2 * (cp < 32 ? cp : 0);
+      step[i] = 16 * (int64_t)ppad;
+      dst[i] = ch * 128;
+    } else {
+      const int u = (ch - 10) * 64 + lane, row = u / 72, cp = u - row * 72;
+      const int col = (cp < 64 && (right || cp < 32)) ? cp : 0;
+      src[i] = U + (int64_t)row * Npad + n0 + 2 * col;
+      step[i] = 16 * (int64_t)Npad;
+      dst[i] = kStageA + (ch - 10) * 128;
+    }
+  }
+  auto request = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      __builtin_amdgcn_global_load_lds(src[i], (__attribute__((address_space(3))) void*)(&stage[b][0] + dst[i]), 16, 0, 0);
+      src[i] += step[i];
+    }
+  };
+
+  v4f64 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
 
-  const int kend = min(Npad, n0 + 64);                       // U[k][n] = 0 for k > n
-  const double* zp = Z + (int64_t)lr * ppad + p0 + lc;
-  const double* up = U + (int64_t)lr * Npad + n0 + lc;
-  double2 za = *(const double2*)zp, zb = *(const double2*)(zp + 2);
-  double2 ua = *(const double2*)up, ub = *(const double2*)(up + 2);
+  const int kend = min(Npad, n0 + 128);                      // U[k][n] = 0 for k > n
+  request(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   int buf = 0;
   for (int k0 = 0; k0 < kend; k0 += 16) {
-    *(double2*)&As[buf][lr][lc] = za; *(double2*)&As[buf][lr][lc + 2] = zb;
-    *(double2*)&Bs[buf][lr][lc] = ua; *(double2*)&Bs[buf][lr][lc + 2] = ub;
-    __syncthreads();
-    if (k0 + 16 < kend) {
-      const double* zn = zp + (int64_t)(k0 + 16) * ppad;
-      const double* un = up + (int64_t)(k0 + 16) * Npad;
-      za = *(const double2*)zn; zb = *(const double2*)(zn + 2);
-      ua = *(const double2*)un; ub = *(const double2*)(un + 2);
-    }
+    if (k0 + 16 < kend) request(buf ^ 1);                     // its last readers passed the barrier that ended the previous iteration
+    const double* As = &stage[buf][0];
+    const double* Bs = As + kStageA;
 #pragma unroll
     for (int kk = 0; kk < 16; kk += 4) {
-      const double a0 = As[buf][kk + l4][wp + l15], a1 = As[buf][kk + l4][wp + 16 + l15];
-      const double b0 = Bs[buf][kk + l4][wn + l15], b1 = Bs[buf][kk + l4][wn + 16 + l15];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      const double a0 = As[(kk + l4) * kTS + wp + l15], a1 = As[(kk + l4) * kTS + wp + 16 + l15];
+      double b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[(kk + l4) * kTS2 + wn + 16 * j + l15];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[j], acc[1][j], 0, 0, 0);
+      }
     }
-    buf ^= 1;   // the other buffer is free: its readers passed the barrier of this iteration
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's chunks of the next stage have landed
+    __syncthreads();
+    buf ^= 1;
   }
 
   // epilogue: field[rec][n] = acc * scale[rec] * mask[n]
@@ -269,7 +311,7 @@ __global__ __launch_bounds__(256) void cz_gemm_kernel(const ProposeArgs a, const
         const double sc = c.scale[rec];
         double* __restrict__ out = a.fields + (int64_t)rec * a.field_stride;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 4; ++j) {
           const int n = n0 + wn + 16 * j + l15;
           if (n < N) out[n] = (acc[i][j][q] * sc) * mask[n];
         }
@@ -398,16 +440,14 @@ hipError_t launch_cholesky_upper(double* A, int n, int ld, double jitter, int* d
 
 hipError_t launch_propose_cholesky(const ProposeArgs& a, const CholArgs& c, hipStream_t st) {
   const int64_t nrec = (int64_t)a.n_chains * a.n_steps;
-  hipError_t e = hipMemsetAsync(c.counts, 0, sizeof(int) * c.n_groups, st);
-  if (e != hipSuccess) return e;
+  if (c.n_groups > 4096) return hipErrorInvalidValue;            // cz_bucket_kernel keeps 2 ints per group in LDS
   const unsigned gb = (unsigned)((nrec + 255) / 256);
   hipLaunchKernelGGL(cz_scalars_kernel, dim3(gb), dim3(256), 0, st, a, c);
-  hipLaunchKernelGGL(cz_scan_kernel, dim3(1), dim3(64), 0, st, a, c);
-  hipLaunchKernelGGL(cz_scatter_kernel, dim3(gb), dim3(256), 0, st, a, c);
+  hipLaunchKernelGGL(cz_bucket_kernel, dim3(1), dim3(1024), sizeof(int) * 2 * c.n_groups, st, a, c);
   const unsigned max_tiles = (unsigned)((nrec + 63) / 64 + c.n_groups);
   const int nmax = a.B.max_bh * a.B.max_bw;
   hipLaunchKernelGGL(cz_zgen_kernel, dim3(max_tiles, 16), dim3(256), 0, st, a, c);
-  hipLaunchKernelGGL(cz_gemm_kernel, dim3(max_tiles * (unsigned)((nmax + 63) / 64)), dim3(256), 0, st, a, c);
+  hipLaunchKernelGGL(cz_gemm_dma_kernel, dim3(max_tiles * (unsigned)((nmax + 127) / 128)), dim3(256), 0, st, a, c);
   return hipGetLastError();
 }
 

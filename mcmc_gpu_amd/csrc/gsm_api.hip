@@ -420,7 +420,7 @@ static int check_propose_ready(gsm_handle h, const gsm_rf_params* rf, const char
 
 // k^2 tables of the spectral amplitude for this resolution (built on first use, rebuilt when the resolution changes)
 static int ensure_k2(gsm_handle h, const gsm_rf_params* rf, hipStream_t st) {
-  if (rf->generator == GSM_GEN_SPECTRAL && !h->d_mathtab) {      // once per handle: the table of math_tables.h
+  if (!h->d_mathtab) {      // once per handle: the table of math_tables.h (Box-Muller of both generators)
     double tab[kMathTabDoubles];
     build_math_tables(tab);
     HIPCHK(h, hipMalloc(&h->d_mathtab, sizeof(tab)));
@@ -446,7 +446,7 @@ static int ensure_chol(gsm_handle h, int slot, size_t recs, CholArgs* out) {
   if (c.recs < recs || c.groups != groups) {
     if (c.ints) { hipFree(c.ints); hipFree(c.zoff); hipFree(c.per_rec); hipFree(c.scale); hipFree(c.zbuf); c = gsm_context::CholScratch(); }
     const size_t nmax_pad = (size_t)((h->B.max_bh * h->B.max_bw + 63) & ~63);
-    HIPCHK(h, hipMalloc(&c.ints, sizeof(int) * (size_t)(5 * groups + 3)));
+    HIPCHK(h, hipMalloc(&c.ints, sizeof(int) * (size_t)(6 * groups + 4)));
     HIPCHK(h, hipMalloc(&c.zoff, sizeof(int64_t) * (size_t)groups));
     HIPCHK(h, hipMalloc(&c.per_rec, sizeof(int) * 2 * recs));
     HIPCHK(h, hipMalloc(&c.scale, sizeof(double) * recs));
@@ -455,7 +455,7 @@ static int ensure_chol(gsm_handle h, int slot, size_t recs, CholArgs* out) {
   }
   out->n_classes = h->n_classes; out->n_groups = groups; out->factors = h->d_factors;
   out->counts = c.ints; out->rec_off = c.ints + groups; out->tile_off = c.ints + 2 * groups + 1;
-  out->cursor = c.ints + 3 * groups + 2; out->work_off = c.ints + 4 * groups + 2; out->z_off = c.zoff;
+  out->work_off = c.ints + 4 * groups + 2; out->z_off = c.zoff;
   out->group_of = c.per_rec; out->order = c.per_rec + recs; out->scale = c.scale; out->zbuf = c.zbuf;
   return GSM_OK;
 }

@@ -129,9 +129,8 @@ struct CholArgs {
   int* counts;                     // [n_groups]
   int* rec_off;                    // [n_groups + 1]
   int* tile_off;                   // [n_groups + 1]
-  int* work_off;                   // [n_groups + 1] prefix of 64 x 64 output tiles (p-tiles x n-tiles) per group
+  int* work_off;                   // [n_groups + 1] prefix of 64 x 128 output tiles (p-tiles x n-tiles) per group
   int64_t* z_off;                  // [n_groups]
-  int* cursor;                     // [n_groups]
   int* group_of;                   // [n_rec]
   int* order;                      // [n_rec]
   double* scale;                   // [n_rec]

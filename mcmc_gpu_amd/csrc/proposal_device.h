@@ -84,6 +84,19 @@ __device__ __forceinline__ void normals2(uint64_t seed, int64_t step, uint32_t s
   g2 = rad * s;
 }
 
+// normals2 for per-LANE seeds (the Cholesky generator's z: every lane of a wave serves another chain)
+__device__ __forceinline__ void normals2_key(uint64_t seed, int64_t step, uint32_t stream, uint32_t idx, double& g1, double& g2,
+                                             const double* mt) {
+  const u32x4 r = philox_draw(seed, step, stream, idx);
+  const double u1 = u01_open0_from(r.x, r.y);
+  const double u2 = u01_from(r.z, r.w);
+  const double rad = sqrt_lean(-2.0 * log_tab(u1, mt));
+  double s, c;
+  sincos_tab(u2, mt, s, c);
+  g1 = rad * c;
+  g2 = rad * s;
+}
+
 // 2*pi*fftfreq(n, d=res)[k] with inv = 1 / (n * res): numpy.fft.fftfreq multiplies the integer frequency by that
 // reciprocal too (MCMC.py:221-222), so this is the reference's value and the division happens once per proposal
 __device__ __forceinline__ double wavenumber(int k, int n, double inv) {

@@ -9,10 +9,15 @@ from mcmc_gpu_amd.engine import _ptr
 ap = argparse.ArgumentParser()
 ap.add_argument('--chains', type=int, default=1024); ap.add_argument('--grid', type=int, default=256)
 ap.add_argument('--steps', type=int, default=8); ap.add_argument('--reps', type=int, default=10)
+ap.add_argument('--generator', default='spectral'); ap.add_argument('--classes', type=int, default=2)
 a = ap.parse_args()
 prob, ch, rf = synthetic.template(a.grid)
 eng = ch._make_engine(rf, a.chains, 0)
 eng.set_state(synthetic.initial_beds(prob, a.chains))
+if a.generator == 'cholesky':
+    from mcmc_gpu_amd import cholesky as chol
+    rf.generator = 'cholesky'
+    chol.build_factors(eng, rf, n_classes=a.classes)
 p = eng.rf_struct(rf)
 seeds = eng._seeds(list(range(7, 7 + a.chains)))
 n = a.chains * a.steps

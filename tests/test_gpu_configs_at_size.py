@@ -1,7 +1,8 @@
 """-m gpu: the BASELINE configs that round 1 only exercised at reduced size, at their size (one GPU's share):
 
   configs[3]  512x512 grid, blocks 50-80, precomputed-Cholesky generator, 2 range classes (N = bh*bw up to 6400: the
-              many-tile triangular regime of cz_gemm_kernel), 256 chains x 32 steps
+              many-tile triangular regime of cz_gemm_dma_kernel), 256 chains x 32 steps with value checks and
+              1024 chains x 64 steps (the bench's launch) with the invariants
   configs[4]  1024x1024 grid, fp32 state / fp64 arithmetic, 512 chains (one GPU's shard of the 4096), 32 steps
 
 The oracle cannot run these sizes in seconds; checked instead: (a) proposal fields of a sample of (size, class) buckets
@@ -74,6 +75,24 @@ def test_config3_cholesky_512_grid_at_size():
     eng.set_state(beds0)
     loss, acc, blk = eng.run_philox(n_steps, step0, seeds, rf, batch=16)
     check_chain_invariants(eng, prob["region_mask"], beds0, loss0, loss, acc, blk, (0, 1, 128, 255))
+    eng.close()
+
+
+def test_config3_cholesky_512_grid_1024_chains():
+    """BASELINE configs[3] at its full chain count (512 x 512 grid x 1024 chains, the bench's batch of 64 steps per launch:
+    65536 proposals bucketed into 50 (size, class) groups of ~1300): the size-independent invariants P1-P4 on the result."""
+    H, n_chains, n_steps, ncls = 512, 1024, 64, 2
+    prob, ch, rf = synthetic.template(H)
+    rf.generator = "cholesky"
+    eng = ch._make_engine(rf, n_chains, 0)
+    chol.build_factors(eng, rf, n_classes=ncls)
+    seeds = [31000 + 3 * c for c in range(n_chains)]
+    beds0 = _device_initial_beds(prob, n_chains, eng.dev, 5)
+    loss0 = eng.set_state(beds0)
+    loss, acc, blk = eng.run_philox(n_steps, 777, seeds, rf, batch=64)
+    assert eng.last_run_fused() == 0
+    assert 0.4 < acc.mean() < 0.75
+    check_chain_invariants(eng, prob["region_mask"], beds0, loss0, loss, acc, blk, (0, 1, 511, 1023))
     eng.close()
 
 
