@@ -125,7 +125,12 @@ def cpu_baseline(H, budget_s=15.0):
             "sample": f"{n_workers} chains x {n_iter - 1} steps, {H}x{H} grid, blocks 50-80, NumPy oracle of MCMC.py:1247-1360 "
                       f"under multiprocessing.Pool({n_workers}); {wall:.1f} s wall incl. pool start; "
                       f"{steps / sum(r[1] for r in res):.0f} steps/s/core in-loop",
-            "accept_rate": float(np.mean([r[2] for r in res]))}
+            "accept_rate": float(np.mean([r[2] for r in res])),
+            # the port avoids some of the reference's full-grid copies: measured in the build container (same core, 256x256,
+            # blocks 50-80): oracle 850 steps/s, imported reference chain_crf.run 672 steps/s
+            "port_speed_vs_reference": 1.26,
+            "note": "the NumPy port runs ~1.26x faster than the reference's own loop on the same core: divide `value` by 1.26 for an "
+                    "estimate of the reference itself"}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -298,40 +303,85 @@ def measure(args, H, n_local, generator, state, inner, batch, steps, warmup, ran
     }
 
 
-def measure_small_scale(H=64, n_chains=4, n_iter=400, cpu_iters=40):
+# sgs_weights_kernel: vector wave-instructions per simulated cell at the driver configuration (48 neighbours: ring search + 49-step
+# Gauss-Jordan in registers), rocprofv3 SQ_INSTS_VALU of profiles/r03_sgs_pmc_256chains.txt / simulated cells of that run
+SGS_VALU_PER_CELL = 5.8e3
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4.25      # wave-instructions/s of the chip: 1024 SIMDs, one fp64-class instruction per 4.25 cycles
+                                            # with four waves per SIMD (profiles/r02_valu_issue_rates.txt)
+
+
+def _simulated_cells(outs, is_data):
+    """Cells simulated by a set of chains: block cells without conditioning data, summed over all iterations (from the block records)."""
+    import numpy as np
+    H, W = is_data.shape
+    free = np.zeros((H + 1, W + 1), dtype=np.int64)
+    free[1:, 1:] = np.cumsum(np.cumsum(~is_data, axis=0), axis=1)
+    tot = 0
+    for o in outs:
+        b = o[6]
+        r0 = np.maximum(0, (b[:, 0] - b[:, 2] / 2).astype(int)); r1 = np.minimum(H, (b[:, 0] + b[:, 2] / 2).astype(int))
+        c0 = np.maximum(0, (b[:, 1] - b[:, 3] / 2).astype(int)); c1 = np.minimum(W, (b[:, 1] + b[:, 3] / 2).astype(int))
+        tot += int((free[r1, c1] - free[r0, c1] - free[r1, c0] + free[r0, c0]).sum())
+    return tot
+
+
+def measure_small_scale(H=64, n_chains=4, n_iter=400, cpu_iters=20):
     """BASELINE configs[0] (smallScaleChain 64x64 grid, 4 chains -- the reference's CPU-runnable case) through the product's
-    small-scale chain on the device: SGS-block Metropolis iterations per second, all chains in one handle."""
+    small-scale chain on the device, with the reference DRIVER's own parameters (smallScaleChain_multiprocessing.py:489-556:
+    set_sgs_param(48, 30e3) at 500 m = 60-cell search half-width, blocks 5-20, Matern, QuantileTransformer(1000), trend):
+    SGS-block Metropolis iterations per second, all chains in one handle; a 256-chain throughput line beside it."""
     import numpy as np
     from mcmc_gpu_amd import sgs, synthetic
     prob, ch = synthetic.sgs_template(H, transform=True)
-    beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(n_chains)]
+    is_data = ~np.isnan(prob["cond_bed"])
+    beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(256)]
     sgs.run_many_sgs(ch, beds[:1], [np.random.default_rng(1)], 20)           # warm-up
     rngs = [np.random.default_rng(900 + i) for i in range(n_chains)]
     t0 = time.perf_counter()
-    out, _ = sgs.run_many_sgs(ch, beds, rngs, n_iter)
+    out, _ = sgs.run_many_sgs(ch, beds[:n_chains], rngs, n_iter)             # replay mode: the drop-in's default (host draws)
     dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out_p, _ = sgs.run_many_sgs(ch, beds[:n_chains], rngs, n_iter, philox_seeds=[7000 + i for i in range(n_chains)])
+    dt_p = time.perf_counter() - t0
+    n_big, it_big = 256, 100
+    t0 = time.perf_counter()
+    out_b, _ = sgs.run_many_sgs(ch, beds[:n_big], [None] * n_big, it_big, philox_seeds=[7000 + i for i in range(n_big)])
+    dt_b = time.perf_counter() - t0
+    cells_b = _simulated_cells(out_b, is_data)
     cpu = None
     if cpu_iters > 0:          # the oracle's restatement of chain_sgs.run (MCMC.py:1599-1911), one chain on one host core
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle"))
         import sgs_oracle as so
-        v = ch._vario()
         cfg = so.SgsConfig(prob["xx"], prob["yy"], prob["surf"], prob["velx"], prob["vely"], prob["dhdt"], prob["smb"], prob["cond_bed"],
-                           prob["data_mask"], np.ones((H, H), dtype=int), prob["region_mask"], prob["resolution"], 60.0,
-                           [0, 0.0, 6000.0, 6000.0, float(v["sill"]), "Exponential", None], [16, 4000.0, False, 0], 3, 8, 3, 8,
+                           prob["data_mask"], np.ones((H, H), dtype=int), prob["region_mask"], prob["resolution"], ch.sigma_mc,
+                           list(ch.vario_param), list(ch.sgs_param), ch.block_min_x, ch.block_max_x, ch.block_min_y, ch.block_max_y,
                            trend=ch.trend if ch.detrend_map else None, nst_trans=ch.nst_trans if ch.do_transform else None)
+        so.STABLE_TIES = True           # equidistant neighbours as the device takes them (DESIGN.md section 8)
         t1 = time.perf_counter()
         ref = so.run_chain_sgs(cfg, beds[0], cpu_iters, np.random.default_rng(900))
         cpu = {"value": cpu_iters / (time.perf_counter() - t1), "unit": "chain-iterations/s", "cores": 1, "kind": "port",
-               "sample": f"1 chain x {cpu_iters} iterations, NumPy oracle of MCMC.py:1599-1911",
-               "first_iterations_equal_device": bool(np.array_equal(ref[4], out[0][4][:cpu_iters]))}
+               "sample": f"1 chain x {cpu_iters} iterations, NumPy oracle of MCMC.py:1599-1911 at the same (driver) parameters",
+               "first_iterations_equal_device": bool(np.array_equal(ref[4], out[0][4][:cpu_iters]) and np.array_equal(ref[6], out[0][6][:cpu_iters]))}
+    ach = cells_b * SGS_VALU_PER_CELL / dt_b
     return {"cpu_baseline": cpu,
             "metric": f"chain-iterations/sec of the small-scale (SGS block) chain on a {H}x{H} grid x {n_chains} chains",
             "value": n_chains * n_iter / dt, "unit": "chain-iterations/s", "n_gpus": 1, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"smallScaleChain {H}x{H} grid, {n_chains} chains, exponential variogram, 16 neighbours, blocks 3-8, "
-                                   f"QuantileTransformer(1000) normal-score transform {'on the device' if ch.do_transform else 'absent (scikit-learn not importable)'} "
-                                   "(BASELINE configs[0], here on the GPU; host draws with the reference's NumPy generator calls)",
+            "config": {"workload": f"smallScaleChain {H}x{H} grid, {n_chains} chains, the reference driver's parameters: Matern variogram "
+                                   "(range 9932.5 m, nu 1.226), 48 neighbours within 30 km (search half-width 60 cells), blocks 5-20, sigma_mc 5, "
+                                   f"detrended, QuantileTransformer(1000) normal-score transform {'on the device' if ch.do_transform else 'absent (scikit-learn not importable)'} "
+                                   "(BASELINE configs[0], here on the GPU; replay mode: host draws with the reference's NumPy generator calls)",
                        "iterations": n_iter},
-            "accept_rate": float(np.mean([o[4].mean() for o in out])), "timed_seconds": dt}
+            "accept_rate": float(np.mean([o[4].mean() for o in out])), "timed_seconds": dt,
+            "philox_mode": {"value": n_chains * n_iter / dt_p, "unit": "chain-iterations/s", "timed_seconds": dt_p,
+                            "accept_rate": float(np.mean([o[4].mean() for o in out_p]))},
+            "throughput_256_chains": {
+                "value": n_big * it_big / dt_b, "unit": "chain-iterations/s", "mode": "philox", "timed_seconds": dt_b,
+                "simulated_cells_per_s": cells_b / dt_b,
+                "roofline": {"bound": "valu_issue", "kernel": "sgs_weights_kernel", "achieved": ach / 1e9, "peak": VALU_ISSUE_PEAK / 1e9,
+                             "unit": "G wave-instructions/s", "frac": ach / VALU_ISSUE_PEAK,
+                             "model": "simulated cells/s x 5.8 k vector wave-instructions per cell (ring search + 49-step Gauss-Jordan in "
+                                      "registers; rocprofv3 SQ_INSTS_VALU, profiles/r03_sgs_pmc_256chains.txt) against 1024 SIMDs x 2.4 GHz / 4.25 "
+                                      "cycles per fp64-class instruction; wall time of the whole iteration (8 launches), not of the kernel alone"}}}
 
 
 def main():
@@ -414,7 +464,7 @@ def main():
             torch.cuda.empty_cache()
         t0 = time.perf_counter()
         try:
-            extras["configs[0] on the device"] = measure_small_scale(cpu_iters=0 if args.no_cpu_baseline else 40)
+            extras["configs[0] on the device"] = measure_small_scale(cpu_iters=0 if args.no_cpu_baseline else 20)
             extras["configs[0] on the device"]["wall_seconds_incl_setup"] = time.perf_counter() - t0
         except Exception as e:
             extras["configs[0] on the device"] = {"error": f"{type(e).__name__}: {e}"}

@@ -8,6 +8,14 @@
 
 namespace gsm {
 
+// hipFuncSetAttribute is per device: one flag per (call site, device) -- `flags` is the call site's static array
+constexpr int kMaxDevices = 64;
+inline bool attr_needed_on_this_device(bool (&flags)[kMaxDevices], int& dev) {
+  dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { dev = -1; return true; }
+  return !flags[dev];
+}
+
 // Static fields shared by every chain of a handle (device pointers, H*W each, row-major).
 struct StaticFields {
   const double* surf;

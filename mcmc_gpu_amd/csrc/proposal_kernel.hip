@@ -181,12 +181,13 @@ hipError_t launch_spectral_from_noise(const ProposeArgs& a, const int32_t* size_
                                       const double* noise_re, const double* noise_im, const double* nugget_field, hipStream_t st) {
   const size_t lds = ((size_t)a.lds_main + 32 + kMathTabDoubles) * sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[kMaxDevices] = {};
+  int attr_dev;
+  if (attr_needed_on_this_device(attr_set, attr_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)spectral_from_noise_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)spectral_from_noise_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (attr_dev >= 0) attr_set[attr_dev] = true;
   }
   hipLaunchKernelGGL(noise_scalars_kernel, dim3((unsigned)((a.n_steps + 255) / 256)), dim3(256), 0, st, a, size_idx, rf_scalars);
   if (wide_table(a)) hipLaunchKernelGGL(spectral_from_noise_kernel<2>, dim3(a.n_steps), dim3(512), lds, st, a, noise_re, noise_im, nugget_field);
@@ -218,13 +219,14 @@ hipError_t launch_propose(const ProposeArgs& a_in, hipStream_t st) {
   const size_t lds = ((size_t)a.lds_main + 32 + kMathTabDoubles) * sizeof(double);
   static int nt = -1;   // GSM_PROPOSE_NT=1024: the fused kernel's workgroup size (tests: bit-identical fields)
   if (nt < 0) { const char* v = getenv("GSM_PROPOSE_NT"); nt = (v && atoi(v) == 1024) ? 1024 : 512; }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[kMaxDevices] = {};
+  int attr_dev;
+  if (attr_needed_on_this_device(attr_set, attr_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)propose_kernel<512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)propose_kernel<1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)propose_kernel<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (attr_dev >= 0) attr_set[attr_dev] = true;
   }
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int64_t nrec = (int64_t)a.n_chains * a.n_steps;

@@ -296,12 +296,13 @@ static hipError_t launch_flux_t(const StepArgs& a, hipStream_t st) {
   const size_t lds = step_flux_lds_bytes(a.tile_cap);
   auto kfast = step_flux_kernel<TS, KT, true>;
   auto kslow = step_flux_kernel<TS, KT, false>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[kMaxDevices] = {};
+  int attr_dev;
+  if (attr_needed_on_this_device(attr_set, attr_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)kfast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kslow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (attr_dev >= 0) attr_set[attr_dev] = true;
   }
   if (a.S.fast_div) hipLaunchKernelGGL(kfast, dim3(a.n_chains), dim3(kNT), lds, st, a);
   else hipLaunchKernelGGL(kslow, dim3(a.n_chains), dim3(kNT), lds, st, a);

@@ -273,13 +273,16 @@ _MSC_FILES = ('loss_mc', 'loss_data', 'loss', 'steps', 'resampled_times', 'block
 
 
 def _msc_load_previous(seed_folder):
-    """Resume state of a small-scale seed folder (reference :299-341): the bed_{k}k.txt file names the iteration count."""
+    """Resume state of a small-scale seed folder (reference :299-341).  The bed_{k}k.txt file name carries floor(count / 1000)
+    as in the reference; the exact iteration count -- what a Philox-mode resume continues its counters from -- is the length of
+    the stored loss record (the reference restarts its label arithmetic from k * 1000, which is the same number whenever
+    n_iter is a multiple of 1000, as in its drivers)."""
     beds = list(seed_folder.glob('bed_*.txt'))
     if not beds:
         return None
     k = int(beds[0].stem.split('_')[1].replace('k', ''))
     prev = {key: np.loadtxt(seed_folder / f'{key}_{k}k.txt') for key in _MSC_FILES}
-    return dict(cumulative=k * 1000, bed=np.loadtxt(beds[0]), results=prev,
+    return dict(cumulative=int(np.atleast_1d(prev['loss']).shape[0]), bed=np.loadtxt(beds[0]), results=prev,
                 delete=[seed_folder / f'bed_{k}k.txt'] + [seed_folder / f'{key}_{k}k.txt' for key in _MSC_FILES])
 
 

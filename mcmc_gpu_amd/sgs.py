@@ -342,12 +342,11 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
         # the same order whatever is accepted), so a batch of iterations is drawn ahead, uploaded once, and simulated /
         # scored / decided (gsm_sgs_decide) / committed on the device back to back.
         philox = philox_seeds is not None
-        if philox and (host_nst is not None or keep_all or track):
-            raise NotImplementedError("Philox mode of the small-scale chain keeps the whole iteration on the device: it needs "
-                                      "only_save_last_bed=True, no sample locations and no host-side transformer")
+        if philox and host_nst is not None:
+            raise NotImplementedError("Philox mode of the small-scale chain keeps the whole iteration on the device: the normal-score "
+                                      "transformer must be scikit-learn's QuantileTransformer (normal output, one feature) or absent")
         batch = int(os.environ.get('GSM_SGS_BATCH', '32')) if (host_nst is None and not keep_all and not track) else 1
         if philox:
-            batch = max(batch, 2)
             if len(philox_seeds) != n:
                 raise ValueError('need one Philox seed per chain')
             d_seeds = torch.as_tensor(np.asarray([int(x) & 0xFFFFFFFFFFFFFFFF for x in philox_seeds], dtype=np.uint64).view(np.int64)).to(dev)
@@ -392,6 +391,13 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
             loss_cache[:, it_done:it_done + kb] = d_lrec.cpu().numpy()
             step_cache[:, it_done:it_done + kb] = d_arec.cpu().numpy()
             blocks_cache[:, it_done:it_done + kb] = d_blk.cpu().numpy().transpose(1, 0, 2)
+            if keep_all or track:                      # per-iteration bed records (chain_sgs.run, MCMC.py:1814-1822): kb == 1 here
+                bed_c = cur.cpu().numpy()
+                if keep_all:
+                    bed_cache[:, it_done] = bed_c + trend if detrend else bed_c
+                if track:
+                    for c in range(n):
+                        sample_values[c, :, it_done] = bed_c[c][ij[:, 0], ij[:, 1]]
             it_done += kb
             if progress_bar is not None:
                 el = time.time() - t0

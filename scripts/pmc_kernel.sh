@@ -18,8 +18,9 @@ acc = collections.defaultdict(list)
 for f in glob.glob(out + "/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if sub in r["Kernel_Name"]:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, v in sorted(acc.items()):
-    print(f"{k:34s} dispatches {len(v):4d}  mean {sum(v) / len(v):.6g}")
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            acc[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (name, k), v in sorted(acc.items()):
+    print(f"{name:40s} {k:30s} dispatches {len(v):5d}  mean {sum(v) / len(v):.6g}  total {sum(v):.6g}")
 PY
 find $out -name "*.db" -delete; find $out -name "*counter_collection.csv" -delete; find $out -name "*agent_info.csv" -delete

@@ -305,6 +305,14 @@ def test_small_scale_driver_philox_mode_segments(tmp_path):
         np.testing.assert_allclose(one[c][0], two[c][0], rtol=0, atol=1e-6)     # the bed passes through a text file between segments
     f = tmp_path / "two" / "LargeScaleChain" / "5" / "SmallScaleChain" / "811"
     assert np.loadtxt(f / "steps_2k.txt").shape == (2000,)
+    # segments that are not multiples of 1000: the resume continues the Philox counters at the exact iteration count (the
+    # length of the stored records), not at the file label's floor(count / 1000) * 1000
+    one = driver.smallScaleChain_mp(3, 1, ch, beds, seeds, 5, [3000] * 3, output_path=str(tmp_path / "one15"), mode='philox')
+    driver.smallScaleChain_mp(3, 1, ch, beds, seeds, 5, [1500] * 3, output_path=str(tmp_path / "two15"), mode='philox')
+    two = driver.smallScaleChain_mp(3, 1, ch, beds, seeds, 5, [1500] * 3, output_path=str(tmp_path / "two15"), mode='philox')
+    for c in range(3):
+        assert np.array_equal(one[c][4][1500:], two[c][4]) and np.array_equal(one[c][6][1500:], two[c][6])
+    assert np.loadtxt(tmp_path / "two15" / "LargeScaleChain" / "5" / "SmallScaleChain" / "811" / "steps_3k.txt").shape == (3000,)
 
 
 def test_small_scale_driver_starts_its_own_ranks(tmp_path, monkeypatch):
@@ -351,3 +359,28 @@ def test_windowed_iteration_end_equals_the_full_grid_path(monkeypatch):
             np.testing.assert_allclose(a[3], b[3], rtol=1e-12)
         acc = np.mean([o[4].mean() for o in res[0]])
         assert 0.05 < acc < 0.95
+
+
+def test_philox_mode_keeps_per_iteration_records():
+    """chain_sgs.run's full signature in Philox mode (MCMC.py:1599, :1814-1829): only_save_last_bed=False returns the bed of every
+    iteration, sample locations their values -- the same chain as the last-bed-only run."""
+    from mcmc_gpu_amd import synthetic
+    n_iter = 60
+    outs = []
+    for keep in (False, True):
+        prob, ch = synthetic.sgs_template(32, transform=True, light=True)
+        ch.set_random_generator(rng_seed=4242)
+        ch.set_rng_mode('philox')
+        if keep:
+            loc = np.array([[prob["xx"][5, 7], prob["yy"][5, 7]], [prob["xx"][20, 11], prob["yy"][20, 11]]])
+            ch.set_sample_points_locations(loc)
+        outs.append(ch.run(n_iter, only_save_last_bed=not keep, info_per_iter=10 ** 9, plot=False, progress_bar=None))
+    last, full = outs
+    assert len(full) == 8 and full[0].shape == (n_iter, 32, 32)
+    assert np.array_equal(full[4], last[4]) and np.array_equal(full[6], last[6]) and np.array_equal(full[3], last[3])
+    assert np.array_equal(full[0][-1], last[0])
+    tr = ch.trend if ch.detrend_map else np.zeros((32, 32))
+    np.testing.assert_allclose(full[7][0, 1:], full[0][1:, 5, 7] - tr[5, 7], rtol=0, atol=1e-9)      # sample values are detrended beds
+    np.testing.assert_allclose(full[7][1, 1:], full[0][1:, 20, 11] - tr[20, 11], rtol=0, atol=1e-9)
+    moved = np.abs(np.diff(full[0], axis=0)).max(axis=(1, 2)) > 0          # the bed changes exactly on accepted iterations
+    assert np.array_equal(moved, full[4][1:].astype(bool))
