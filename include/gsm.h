@@ -149,6 +149,25 @@ int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, const uint6
                        const gsm_rf_params* rf, int32_t* size_idx, int32_t* centre, double* u,
                        double* fields, int64_t field_stride, double* rf_scalars, void* stream);
 
+/* The reference's OWN random numbers on the device ('pcg64' draw mode): every chain's two numpy.random.Generator(PCG64) streams --
+ * RandField.rng and the chain's generator, SURVEY.md section 8 a13 -- advanced by n_steps Metropolis steps' worth of draws in the
+ * reference's call order, bit for bit what NumPy returns on the host (PCG64 XSL-RR, the 32-bit half cache of integers(), Lemire's
+ * bounded integers, uniform, the 256-layer ziggurat normal incl. libm's log1p in its tail: mcmc_gpu_amd/csrc/pcg64_device.h,
+ * restated in oracle/pcg64_oracle.py and pinned there against NumPy itself).
+ *   rf_state, chain_state [dev, n_chains*6] in/out   per generator: state lo, state hi, inc lo, inc hi, has_uint32, uinteger -- the
+ *                                                   integers of numpy's bit_generator.state dict
+ *   region_mask [dev, H*W] or NULL                   centre rejection of MCMC.py:1253-1258 (NULL: update_in_region False)
+ * Outputs, record r = c * n_steps + s: size_idx[r] (RandField.rng.integers(0, n_sizes), MCMC.py:755), rf_scalars[4 r] = (scale / 3,
+ * nugget, range_x, range_y) (MCMC.py:199-207), noise_re / noise_im / nugget_field at r * field_stride: the rng.normal planes of
+ * MCMC.py:242 and :251, row-major (bh, bw) (nugget_field may be NULL when rf->nugget_max == 0: the draws are consumed, nothing is
+ * stored), centre[2 r] (row, col) and u[r] (MCMC.py:1336).  Feed them to gsm_spectral_from_noise and gsm_run_replay: the chain
+ * then follows the CPU reference on the same seeds -- accept masks identical, beds / losses to the 1e-12 x scale of the device's
+ * inverse DFT against pocketfft -- without any host draw.  Synchronises the stream.
+ * Replaces: the numpy.random calls of RandField.get_rfblock / spectral_synthesis_field / chain_crf.run listed above. */
+int gsm_draw_pcg64(gsm_handle h, int32_t n_steps, const gsm_rf_params* rf, uint64_t* rf_state, uint64_t* chain_state,
+                   const uint8_t* region_mask, int32_t* size_idx, int32_t* centre, double* u, double* rf_scalars,
+                   double* noise_re, double* noise_im, double* nugget_field, int64_t field_stride, void* stream);
+
 /* The spectral synthesis alone, fed with CALLER-SUPPLIED white noise instead of Philox draws: the value pin of the device
  * arithmetic against the reference's.  For field r of n_fields:
  *   size_idx   [dev, n_fields]                 block-table index -> shape (bh, bw)

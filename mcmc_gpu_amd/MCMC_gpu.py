@@ -393,9 +393,13 @@ class chain_crf_gpu:
         self.crf_data_weight = RF.get_crf_weight(self.xx, self.yy, self.data_mask)[0]
 
     def set_rng_mode(self, mode, philox_batch=None):
-        """'replay' (NumPy draws, reference-identical chain) or 'philox' (device draws)."""
-        if mode not in ('replay', 'philox'):
-            raise ValueError("mode must be 'replay' or 'philox'")
+        """'replay': NumPy draws and NumPy spectral synthesis on the host, the device does the step -- the reference-identical
+        chain, bit for bit.  'pcg64': the SAME NumPy generator streams advanced on the device (gsm_draw_pcg64) and the device's
+        spectral synthesis: the reference's draws, block records and accept decisions on the same seeds without host work per
+        step (beds / losses to the accuracy of the device's inverse DFT).  'philox': counter-based device draws, a chain of its
+        own definition (throughput mode)."""
+        if mode not in ('replay', 'philox', 'pcg64'):
+            raise ValueError("mode must be 'replay', 'pcg64' or 'philox'")
         self.rng_mode = mode
         if philox_batch:
             self.philox_batch = int(philox_batch)
@@ -470,13 +474,39 @@ class chain_crf_gpu:
             if track:
                 sample_values[:, 0] = bed0[ij[:, 0], ij[:, 1]]
             per_step = keep_all or track
-            chunk = 1 if per_step else (self.replay_chunk if self.rng_mode == 'replay' else max(n_iter - 1, 1))
+            chunk = 1 if per_step else (self.replay_chunk if self.rng_mode in ('replay', 'pcg64') else max(n_iter - 1, 1))
+            if self.rng_mode == 'pcg64':
+                import ctypes as C
+                import torch
+                from .engine import GsmEngine, _ptr
+                p64 = eng.rf_struct(RF)
+                d_rf = torch.as_tensor(GsmEngine.pack_pcg64_states([RF.rng]).view(np.int64)).to(eng.dev)
+                d_ch = torch.as_tensor(GsmEngine.pack_pcg64_states([self.rng]).view(np.int64)).to(eng.dev)
+                d_reg = (torch.as_tensor(np.ascontiguousarray(np.asarray(self.region_mask) == 1, dtype=np.uint8)).to(eng.dev)
+                         if self.update_in_region else None)
             t0 = time.time()
             done = 1
             next_info = info_per_iter
             while done < n_iter:
                 n = min(chunk, n_iter - done)
-                if self.rng_mode == 'replay':
+                if self.rng_mode == 'pcg64':
+                    d = eng.draw_pcg64(n, p64, d_rf, d_ch, d_reg)
+                    fl = torch.zeros((1, n, eng.field_stride), dtype=torch.float64, device=eng.dev)
+                    l_b = torch.empty((1, n), dtype=torch.float64, device=eng.dev)
+                    a_b = torch.empty((1, n), dtype=torch.uint8, device=eng.dev)
+                    with torch.cuda.device(eng.dev):
+                        eng._check(eng.lib.gsm_spectral_from_noise(eng.h, n, _ptr(d['size_idx']), _ptr(d['rf_scalars']), C.byref(p64),
+                                                                   _ptr(d['noise_re']), _ptr(d['noise_im']), _ptr(d['nugget']), _ptr(fl),
+                                                                   eng.field_stride, eng._stream()))
+                        eng._check(eng.lib.gsm_run_replay(eng.h, n, _ptr(eng.beds), _ptr(eng.energy), _ptr(eng.resampled), _ptr(eng.loss_sum),
+                                                          _ptr(d['size_idx']), _ptr(d['centre']), _ptr(d['u']), _ptr(fl), eng.field_stride,
+                                                          _ptr(l_b), _ptr(a_b), eng._stream()))
+                    loss, acc = l_b.cpu().numpy(), a_b.cpu().numpy()
+                    si = d['size_idx'][0].cpu().numpy()
+                    blocks_cache[done:done + n, 0:2] = d['centre'][0].cpu().numpy()
+                    blocks_cache[done:done + n, 2] = eng.bh[si]
+                    blocks_cache[done:done + n, 3] = eng.bw[si]
+                elif self.rng_mode == 'replay':
                     si, ce, u, fields = self._draw_chunk(RF, n)
                     loss, acc = eng.run_replay(si[None], ce[None], u[None], eng.pack_fields([fields]))
                     blocks_cache[done:done + n, 0:2] = ce
@@ -504,6 +534,9 @@ class chain_crf_gpu:
                           file=sys.stdout, flush=True)
             bed_c = eng.beds[0].double().cpu().numpy()
             resampled = eng.resampled[0].cpu().numpy().astype(np.float64)
+            if self.rng_mode == 'pcg64':           # the generators continue where the device left them, as after NumPy calls
+                RF.rng.bit_generator.state = GsmEngine.unpack_pcg64_states(d_rf.cpu().numpy().view(np.uint64))[0]
+                self.rng.bit_generator.state = GsmEngine.unpack_pcg64_states(d_ch.cpu().numpy().view(np.uint64))[0]
         finally:
             eng.close()
         loss_mc_cache = loss_cache.copy()
@@ -639,6 +672,87 @@ def run_many_replay(chain, RF, initial_beds, rf_states, chain_states, n_iter, ch
         bc = np.vstack([np.full((1, 4), np.nan), blocks[c]])
         out.append((beds_out[c], lc.copy(), np.zeros(n_iter), lc, sc, res[c], bc))
     return out, rf_states, chain_states
+
+
+def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, batch=None, device=None, progress=False):
+    """The 'pcg64' draw mode: run_many_replay with NO host draws.  Chain c's two NumPy generators (rf_states[c], chain_states[c]:
+    `Generator.bit_generator.state` dicts of PCG64 generators) are advanced ON THE DEVICE, bit for bit as NumPy advances them
+    (gsm_draw_pcg64: PCG64, the 32-bit half cache of integers(), Lemire's bounded integers, uniform, the ziggurat normal), in
+    the reference's call order; the white-noise planes go through the device spectral synthesis (gsm_spectral_from_noise,
+    value-pinned to the reference's spectral_synthesis_field at 1e-12 x scale) and the fields through gsm_run_replay.  Same
+    return value as run_many_replay.  Against the CPU reference on the same seeds: block records, the draws and the final
+    generator states are identical; accept masks are identical unless an accept uniform falls within ~1e-12 of its threshold;
+    beds and losses agree to the accuracy of the device's inverse DFT against pocketfft (tests/test_gpu_pcg64.py)."""
+    import ctypes as C
+    import torch
+    from .engine import GsmEngine, _ptr
+    if not isinstance(RF, RandField):
+        raise TypeError('The arugment "RF" has to be an object of the class RandField')
+    if not getattr(RF, 'spectral', False):
+        raise NotImplementedError('only the spectral-synthesis generator (set_generation_method(True)) is built')
+    beds = np.asarray(initial_beds, dtype=np.float64)
+    n_chains = beds.shape[0]
+    if len(rf_states) != n_chains or len(chain_states) != n_chains:
+        raise ValueError('need one RandField and one chain generator state per chain')
+    n_iter = int(n_iter)
+    n_steps = n_iter - 1
+    eng = chain._make_engine(RF, n_chains, device)
+    try:
+        dev = eng.dev
+        loss0 = eng.set_state(beds)
+        p = eng.rf_struct(RF)
+        d_rf = torch.as_tensor(GsmEngine.pack_pcg64_states(list(rf_states)).view(np.int64)).to(dev)
+        d_ch = torch.as_tensor(GsmEngine.pack_pcg64_states(list(chain_states)).view(np.int64)).to(dev)
+        d_reg = (torch.as_tensor(np.ascontiguousarray(np.asarray(chain.region_mask) == 1, dtype=np.uint8)).to(dev)
+                 if chain.update_in_region else None)
+        stride = eng.field_stride
+        if batch is None:      # three noise planes + the fields of a batch: at most ~2 GiB
+            batch = int(max(1, min(256, (2 << 30) // (4 * n_chains * stride * 8))))
+        batch = max(1, min(int(batch), max(n_steps, 1)))
+        loss = torch.empty((n_chains, max(n_steps, 1)), dtype=torch.float64, device=dev)
+        acc = torch.empty((n_chains, max(n_steps, 1)), dtype=torch.uint8, device=dev)
+        blocks = np.zeros((n_chains, n_steps, 4))
+        fields = torch.zeros((n_chains, batch, stride), dtype=torch.float64, device=dev)
+        t0 = time.time()
+        done = 0
+        while done < n_steps:
+            n = min(batch, n_steps - done)
+            d = eng.draw_pcg64(n, p, d_rf, d_ch, d_reg)
+            fl = fields if n == batch else torch.zeros((n_chains, n, stride), dtype=torch.float64, device=dev)
+            l_b = torch.empty((n_chains, n), dtype=torch.float64, device=dev)
+            a_b = torch.empty((n_chains, n), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                eng._check(eng.lib.gsm_spectral_from_noise(eng.h, n_chains * n, _ptr(d['size_idx']), _ptr(d['rf_scalars']), C.byref(p),
+                                                           _ptr(d['noise_re']), _ptr(d['noise_im']), _ptr(d['nugget']), _ptr(fl), stride,
+                                                           eng._stream()))
+                eng._check(eng.lib.gsm_run_replay(eng.h, n, _ptr(eng.beds), _ptr(eng.energy), _ptr(eng.resampled), _ptr(eng.loss_sum),
+                                                  _ptr(d['size_idx']), _ptr(d['centre']), _ptr(d['u']), _ptr(fl), stride,
+                                                  _ptr(l_b), _ptr(a_b), eng._stream()))
+            loss[:, done:done + n] = l_b
+            acc[:, done:done + n] = a_b
+            si = d['size_idx'].cpu().numpy()
+            blocks[:, done:done + n, 0:2] = d['centre'].cpu().numpy()
+            blocks[:, done:done + n, 2] = eng.bh[si]
+            blocks[:, done:done + n, 3] = eng.bw[si]
+            done += n
+            if progress:
+                print(f"{n_chains} chains: {100 * done / n_steps:3.0f}% | chain-it/s: {n_chains * done / max(time.time() - t0, 1e-9):9.1f}",
+                      file=sys.stdout, flush=True)
+        loss_h = loss[:, :n_steps].cpu().numpy()
+        acc_h = acc[:, :n_steps].cpu().numpy()
+        rf_out = GsmEngine.unpack_pcg64_states(d_rf.cpu().numpy().view(np.uint64))
+        ch_out = GsmEngine.unpack_pcg64_states(d_ch.cpu().numpy().view(np.uint64))
+        beds_out = eng.beds.double().cpu().numpy()
+        res = eng.resampled.cpu().numpy().astype(np.float64)
+    finally:
+        eng.close()
+    out = []
+    for c in range(n_chains):
+        lc = np.concatenate([[loss0[c]], loss_h[c]])
+        sc = np.concatenate([[0.0], acc_h[c].astype(np.float64)])
+        bc = np.vstack([np.full((1, 4), np.nan), blocks[c]])
+        out.append((beds_out[c], lc.copy(), np.zeros(n_iter), lc, sc, res[c], bc))
+    return out, rf_out, ch_out
 
 
 def init_lsc_chain_by_instance(param_dict):

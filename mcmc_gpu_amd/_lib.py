@@ -16,7 +16,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libgsm_hip.so"
 HEADER = PKG_DIR.parent / "include" / "gsm.h"
-SOURCES = ["gsm_api.hip", "gsm_version.hip", "step_kernel.hip", "step_flux_kernel.hip", "chain_fused_kernel.hip", "proposal_kernel.hip", "cholesky_kernel.hip", "sgs_kernel.hip"]
+SOURCES = ["gsm_api.hip", "gsm_version.hip", "step_kernel.hip", "step_flux_kernel.hip", "chain_fused_kernel.hip", "proposal_kernel.hip", "cholesky_kernel.hip", "sgs_kernel.hip", "pcg64_kernel.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-Wno-unused-value", "-Wno-unused-result"]
 # per-file extras.  step_flux_kernel: without machine LICM the fp64 polynomial constants of exp() are materialised at
@@ -199,6 +199,7 @@ def load() -> C.CDLL:
     lib.gsm_sgs_commit.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.gsm_sgs_blocks_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, dbl, i32, dbl, vp, vp, vp, vp, i32, vp]
     lib.gsm_sgs_check.argtypes = [vp, vp]
+    lib.gsm_draw_pcg64.argtypes = [vp, i32, C.POINTER(RfParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.gsm_sgs_state_init.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.gsm_sgs_finish.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.gsm_sgs_draw_philox.argtypes = [vp, vp, i64, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]

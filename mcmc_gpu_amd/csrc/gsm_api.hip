@@ -33,6 +33,7 @@ struct gsm_context {
   double* d_sgs_part_sum = nullptr; int32_t* d_sgs_part_bad = nullptr; size_t sgs_part_cap = 0;   // gsm_sgs_loss partial sums
   // gsm_sgs_blocks scratch: visiting ranks + one record per (chain, cell slot), see SgsArgs
   void* d_sgs_rec = nullptr; size_t sgs_rec_cells = 0;
+  uint64_t* d_pcg_tab = nullptr;   // gsm_draw_pcg64: LCG jump table (512 words) + ziggurat tables (768 words)
   int32_t* d_k2_off = nullptr;
   double k2_resolution = 0.0;
   PropScalars* d_scalars[2] = {nullptr, nullptr};
@@ -136,6 +137,7 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_mathtab) hipFree(h->d_mathtab);
   if (h->d_sgs_part_sum) { hipFree(h->d_sgs_part_sum); hipFree(h->d_sgs_part_bad); }
   if (h->d_sgs_rec) hipFree(h->d_sgs_rec);
+  if (h->d_pcg_tab) hipFree(h->d_pcg_tab);
   if (h->d_k2_off) hipFree(h->d_k2_off);
   if (h->d_factors) hipFree(h->d_factors);
   for (auto& c : h->chol) { if (c.ints) hipFree(c.ints); if (c.zoff) hipFree(c.zoff); if (c.per_rec) hipFree(c.per_rec);
@@ -771,6 +773,38 @@ extern "C" int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* co
   HIPCHK(h, hipStreamSynchronize(st));
   h->n_classes = n_classes;
   return GSM_OK;
+}
+
+extern "C" int gsm_draw_pcg64(gsm_handle h, int32_t n_steps, const gsm_rf_params* rf, uint64_t* rf_state, uint64_t* chain_state,
+                              const uint8_t* region_mask, int32_t* size_idx, int32_t* centre, double* u, double* rf_scalars,
+                              double* noise_re, double* noise_im, double* nugget_field, int64_t field_stride, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!h->have_blocks) return fail(h, GSM_E_STATE, "gsm_draw_pcg64: call gsm_set_blocks first");
+  if (!rf || !rf_state || !chain_state || !size_idx || !centre || !u || !rf_scalars || !noise_re || !noise_im)
+    return fail(h, GSM_E_ARG, "gsm_draw_pcg64: NULL pointer");
+  if (n_steps < 1) return fail(h, GSM_E_ARG, "gsm_draw_pcg64: n_steps must be >= 1");
+  if (field_stride < (int64_t)h->B.max_bh * h->B.max_bw) return fail(h, GSM_E_ARG, "gsm_draw_pcg64: field_stride too small");
+  if (rf->nugget_max > 0.0 && !nugget_field) return fail(h, GSM_E_ARG, "gsm_draw_pcg64: nugget_max > 0 needs nugget_field");
+  if (h->B.n_sizes < 1 || (int64_t)h->H >= 0xFFFFFFFFll) return fail(h, GSM_E_ARG, "gsm_draw_pcg64: bad block table / grid");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->d_pcg_tab) {
+    std::vector<uint64_t> tab(4 * 128 + 768);
+    const uint64_t* zig = nullptr;
+    pcg64_host_tables(tab.data(), &zig);
+    memcpy(tab.data() + 512, zig, 768 * sizeof(uint64_t));
+    HIPCHK(h, hipMalloc(&h->d_pcg_tab, tab.size() * sizeof(uint64_t)));
+    HIPCHK(h, hipMemcpy(h->d_pcg_tab, tab.data(), tab.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
+  PcgDrawArgs a{};
+  a.H = h->H; a.W = h->W; a.n_chains = h->n_chains; a.n_steps = n_steps; a.n_sizes = h->B.n_sizes; a.rf = *rf;
+  a.bh = h->B.bh; a.bw = h->B.bw; a.rf_state = rf_state; a.ch_state = chain_state; a.region_mask = region_mask;
+  a.jump = h->d_pcg_tab; a.zig = h->d_pcg_tab + 512;
+  a.size_idx = size_idx; a.centre = centre; a.u = u; a.rf_scalars = rf_scalars;
+  a.noise_re = noise_re; a.noise_im = noise_im; a.nugget = (rf->nugget_max > 0.0) ? nugget_field : nullptr; a.field_stride = field_stride;
+  a.err = h->d_err;
+  HIPCHK(h, launch_pcg64_draw(a, st));
+  return check_device_flag(h, st, "gsm_draw_pcg64");
 }
 
 static int sgs_fill(gsm_handle h, SgsArgs& a, double* grids, const double* zcond, const int32_t* windows, const double* x_axis,

@@ -145,6 +145,23 @@ struct CholArgs {
   double* zbuf;                    // sum over groups of Npad * ppad doubles
 };
 
+// gsm_draw_pcg64 (pcg64_kernel.hip): NumPy's PCG64 generator streams of the reference's chains, on the device
+struct PcgDrawArgs {
+  int H, W, n_chains, n_steps, n_sizes;
+  gsm_rf_params rf;
+  const int32_t* bh; const int32_t* bw;          // block table
+  uint64_t* rf_state;                            // [n_chains*6] state lo, hi, inc lo, hi, has_uint32, uinteger (in/out)
+  uint64_t* ch_state;                            // same for the chain's generator
+  const uint8_t* region_mask;                    // [H*W] or nullptr (update_in_region False)
+  const uint64_t* jump; const uint64_t* zig;     // device copies of the constant tables
+  int32_t* size_idx; int32_t* centre; double* u; double* rf_scalars;
+  double* noise_re; double* noise_im; double* nugget;   // nugget may be nullptr (draws consumed, nothing stored)
+  int64_t field_stride;
+  int32_t* err;
+};
+hipError_t launch_pcg64_draw(const PcgDrawArgs& a, hipStream_t st);
+void pcg64_host_tables(uint64_t* jump_out, const uint64_t** zig_out);
+
 // small-scale chain: sequential Gaussian simulation of one block per chain (sgs_kernel.hip)
 struct SgsCellHdr {          // one per (chain, cell slot), written by sgs_weights_kernel
   int32_t n;                 // neighbours; -1: the cell holds conditioning data; -2: cell outside its window; 0: error

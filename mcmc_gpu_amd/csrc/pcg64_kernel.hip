@@ -1,0 +1,78 @@
+// gsm_draw_pcg64: the random draws of the reference's large-scale chain made ON THE DEVICE from NumPy's own generator streams.
+//
+// Per Metropolis step the reference consumes two numpy.random.Generator(PCG64) objects:
+//   RandField.rng   integers(0, n_sizes, size=1) (MCMC.py:755); uniform x 3 (isotropic) or 4 (scale, nugget, ranges: :199-207);
+//                   normal(size=(bh, bw)) twice (:242); normal(0, sqrt(nug), size=(bh, bw)) (:251, drawn even when nug = 0)
+//   chain.rng       integers(0, H, size=1), integers(0, W, size=1) until region_mask == 1 (:1254-1258); random() (:1336)
+// One 64-lane workgroup per chain walks both streams step after step (pcg64_device.h): the same numbers, bit for bit, that the
+// host mirror (mcmc_gpu_amd/MCMC_gpu.py: draw_chunk) gets from NumPy -- tests/test_gpu_pcg64.py -- at ~10^7 chain-steps/s instead
+// of the ~3 k per host core.  The white-noise planes go to gsm_spectral_from_noise, the scalars to gsm_run_replay.
+#include "gsm_internal.h"
+#include "pcg64_device.h"
+#include "ziggurat_tables.h"
+#include <math.h>
+
+namespace gsm {
+
+__global__ __launch_bounds__(64) void pcg64_draw_kernel(const PcgDrawArgs a) {
+  __shared__ uint64_t jump[4 * pcg::kJump];
+  __shared__ uint64_t zig[kZigTabWords];
+  const int lane = threadIdx.x, chain = blockIdx.x;
+  for (int i = lane; i < 4 * pcg::kJump; i += 64) jump[i] = a.jump[i];
+  for (int i = lane; i < kZigTabWords; i += 64) zig[i] = a.zig[i];
+  __syncthreads();
+  pcg::Stream R, C;
+  uint64_t* rs = a.rf_state + 6 * (size_t)chain;
+  uint64_t* cs = a.ch_state + 6 * (size_t)chain;
+  R.s = pcg::u128{rs[0], rs[1]}; R.inc = pcg::u128{rs[2], rs[3]}; R.has32 = (uint32_t)rs[4]; R.cached = (uint32_t)rs[5];
+  C.s = pcg::u128{cs[0], cs[1]}; C.inc = pcg::u128{cs[2], cs[3]}; C.has32 = (uint32_t)cs[4]; C.cached = (uint32_t)cs[5];
+  R.jump = C.jump = jump; R.zig = C.zig = zig;
+  // this lane's jump constants of the RandField stream: lane + 1 draws ahead
+  const pcg::u128 A_l{jump[4 * lane], jump[4 * lane + 1]};
+  const pcg::u128 C_l = pcg::mul128(pcg::u128{jump[4 * lane + 2], jump[4 * lane + 3]}, R.inc);
+  const gsm_rf_params& P = a.rf;
+  for (int s = 0; s < a.n_steps; ++s) {
+    const int64_t rec = (int64_t)chain * a.n_steps + s;
+    const int si = (int)R.bounded((uint32_t)a.n_sizes);
+    const int bh = a.bh[si], bw = a.bw[si], B = bh * bw;
+    const double scale = R.uniform(P.scale_min, P.scale_max) / 3.0;
+    const double nug = R.uniform(0.0, P.nugget_max);
+    double rx, ry;
+    if (!P.isotropic) { rx = R.uniform(P.range_min_x, P.range_max_x); ry = R.uniform(P.range_min_y, P.range_max_y); }
+    else { rx = R.uniform(P.range_min_x, P.range_max_x); ry = rx; }
+    R.normals(B, 0.0, 1.0, a.noise_re + rec * a.field_stride, lane, A_l, C_l);
+    R.normals(B, 0.0, 1.0, a.noise_im + rec * a.field_stride, lane, A_l, C_l);
+    R.normals(B, 0.0, sqrt(nug), a.nugget ? a.nugget + rec * a.field_stride : nullptr, lane, A_l, C_l);
+    int ix = 0, iy = 0;
+    for (int tries = 0;; ++tries) {
+      ix = (int)C.bounded((uint32_t)a.H);
+      iy = (int)C.bounded((uint32_t)a.W);
+      if (!a.region_mask || a.region_mask[ix * a.W + iy] == 1) break;
+      if (tries > (1 << 20)) { if (lane == 0) atomicOr(a.err, 128); break; }
+    }
+    const double uu = C.next_double();
+    if (lane == 0) {
+      a.size_idx[rec] = si;
+      a.centre[2 * rec] = ix; a.centre[2 * rec + 1] = iy;
+      a.u[rec] = uu;
+      a.rf_scalars[4 * rec] = scale; a.rf_scalars[4 * rec + 1] = nug; a.rf_scalars[4 * rec + 2] = rx; a.rf_scalars[4 * rec + 3] = ry;
+    }
+  }
+  if (lane == 0) {
+    rs[0] = R.s.lo; rs[1] = R.s.hi; rs[4] = R.has32; rs[5] = R.cached;
+    cs[0] = C.s.lo; cs[1] = C.s.hi; cs[4] = C.has32; cs[5] = C.cached;
+  }
+}
+
+hipError_t launch_pcg64_draw(const PcgDrawArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(pcg64_draw_kernel, dim3(a.n_chains), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+// the two constant tables (host side): jump table of the LCG and the ziggurat tables
+void pcg64_host_tables(uint64_t* jump_out, const uint64_t** zig_out) {
+  pcg::build_jump_table(jump_out);
+  *zig_out = kZigTab;
+}
+
+}  // namespace gsm

@@ -152,6 +152,9 @@ def _run_shard(lo, hi, largeScaleChain, rf, initial_beds, rng_seeds, n_iters, ou
             local, rf_st, ch_st = MCMC_gpu.run_many_replay(largeScaleChain, rf, beds, rf_st, ch_st, n_iter,
                                                            n_workers=n_workers if n_workers and n_workers > 0 else None)
             steps1 = steps0
+        elif mode == 'pcg64':
+            local, rf_st, ch_st = MCMC_gpu.run_many_pcg64(largeScaleChain, rf, beds, rf_st, ch_st, n_iter)
+            steps1 = steps0
         else:
             local = None
         if local is not None:
@@ -223,6 +226,9 @@ def largeScaleChain_mp(n_chains, n_workers, largeScaleChain, rf, initial_beds, r
     generators exactly as the reference's pool workers do, so results and checkpoint files equal the CPU driver's; all
     chains of a rank share one handle, and `n_workers` host processes (the reference's argument; <= 0 or None: physical
     cores - 1) draw the proposals of the next chunk while the device steps the current one.
+    mode 'pcg64': the same NumPy generator streams advanced on the device (gsm_draw_pcg64) with the device's spectral synthesis:
+    the reference's draws, block records, accept decisions and generator-state files on the same seeds, no host draw per step
+    (beds / losses to the accuracy of the device's inverse DFT against pocketfft).
     mode 'philox': all chains of this rank advance together in one handle with device-generated proposals.
 
     n_gpus: None = every visible GPU.  With more than one and no torch.distributed group in this process, the function

@@ -287,6 +287,48 @@ class GsmEngine:
         return [h[r, :int(self.bh[size_idx[r]] * self.bw[size_idx[r]])].reshape(int(self.bh[size_idx[r]]), int(self.bw[size_idx[r]]))
                 for r in range(n)]
 
+    # ---- 'pcg64' draw mode: NumPy's generator streams on the device (gsm_draw_pcg64) ------------------------------------
+    @staticmethod
+    def pack_pcg64_states(gens):
+        """[n, 6] uint64 from numpy Generators / bit_generator.state dicts: state lo, hi, inc lo, hi, has_uint32, uinteger."""
+        out = np.zeros((len(gens), 6), dtype=np.uint64)
+        m = (1 << 64) - 1
+        for i, g in enumerate(gens):
+            st = g if isinstance(g, dict) else g.bit_generator.state
+            if st.get("bit_generator") != "PCG64":
+                raise ValueError("the pcg64 draw mode needs numpy.random.Generator(PCG64) generators (numpy.random.default_rng)")
+            s, inc = int(st["state"]["state"]), int(st["state"]["inc"])
+            out[i] = [s & m, s >> 64, inc & m, inc >> 64, int(st["has_uint32"]), int(st["uinteger"])]
+        return out
+
+    @staticmethod
+    def unpack_pcg64_states(words):
+        """numpy bit_generator.state dicts from [n, 6] uint64 (assign to generator.bit_generator.state)."""
+        return [{"bit_generator": "PCG64", "state": {"state": int(w[0]) | (int(w[1]) << 64), "inc": int(w[2]) | (int(w[3]) << 64)},
+                 "has_uint32": int(w[4]), "uinteger": int(w[5])} for w in np.asarray(words, dtype=np.uint64)]
+
+    def draw_pcg64(self, n_steps, rf, d_rf_state, d_chain_state, d_region_mask=None):
+        """n_steps Metropolis steps' worth of the reference's NumPy draws for every chain, on the device.  d_rf_state /
+        d_chain_state: int64 device tensors [n_chains, 6] (pack_pcg64_states), advanced in place.  Returns device tensors
+        size_idx [n, s], centre [n, s, 2], u [n, s], rf_scalars [n, s, 4], noise_re / noise_im [n, s, field_stride] and
+        nugget (or None)."""
+        p = rf if isinstance(rf, RfParams) else self.rf_struct(rf)
+        n = self.n_chains * n_steps
+        si = torch.empty(n, dtype=torch.int32, device=self.dev)
+        ce = torch.empty(n * 2, dtype=torch.int32, device=self.dev)
+        u = torch.empty(n, dtype=torch.float64, device=self.dev)
+        sc = torch.empty(n * 4, dtype=torch.float64, device=self.dev)
+        shape = (self.n_chains, n_steps, self.field_stride)
+        re = torch.zeros(shape, dtype=torch.float64, device=self.dev)
+        im = torch.zeros(shape, dtype=torch.float64, device=self.dev)
+        ng = torch.zeros(shape, dtype=torch.float64, device=self.dev) if p.nugget_max > 0.0 else None
+        with torch.cuda.device(self.dev):
+            self._check(self.lib.gsm_draw_pcg64(self.h, int(n_steps), C.byref(p), _ptr(d_rf_state), _ptr(d_chain_state),
+                                                _ptr(d_region_mask), _ptr(si), _ptr(ce), _ptr(u), _ptr(sc), _ptr(re), _ptr(im),
+                                                _ptr(ng), self.field_stride, self._stream()))
+        return dict(size_idx=si.view(self.n_chains, n_steps), centre=ce.view(self.n_chains, n_steps, 2),
+                    u=u.view(self.n_chains, n_steps), rf_scalars=sc.view(self.n_chains, n_steps, 4), noise_re=re, noise_im=im, nugget=ng)
+
     def enable_timing(self, on=True):
         self._check(self.lib.gsm_enable_timing(self.h, 1 if on else 0))
 

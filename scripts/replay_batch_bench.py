@@ -12,13 +12,14 @@ if __name__ == "__main__":
     ap.add_argument('--chains', type=int, default=64); ap.add_argument('--iters', type=int, default=1000)
     ap.add_argument('--grid', type=int, default=256); ap.add_argument('--serial-chains', type=int, default=4)
     ap.add_argument('--workers', type=int, default=0)
+    ap.add_argument('--mode', default='replay', help="'replay' (host NumPy draws) or 'pcg64' (the same generator streams on the device)")
     a = ap.parse_args()
     prob, ch, rf = synthetic.template(a.grid)
     seeds = [5000 + i for i in range(a.chains)]
     beds = list(synthetic.initial_beds(prob, a.chains))
     with tempfile.TemporaryDirectory() as td:
         t0 = time.time()
-        res = driver.largeScaleChain_mp(a.chains, a.workers, ch, rf, beds, seeds, [a.iters] * a.chains, output_path=td + '/b', n_gpus=1)
+        res = driver.largeScaleChain_mp(a.chains, a.workers, ch, rf, beds, seeds, [a.iters] * a.chains, output_path=td + '/b', n_gpus=1, mode=a.mode)
         t_batched = time.time() - t0
         t0 = time.time()
         ser = []
@@ -29,6 +30,10 @@ if __name__ == "__main__":
                                                            progress_bar=False, chain_id=i, tqdm_position=1, seed=seeds[i], output_path=td + '/s')))
         t_serial = (time.time() - t0) * a.chains / a.serial_chains
     same = all(np.array_equal(x, y, equal_nan=True) for i in range(a.serial_chains) for x, y in zip(res[i], ser[i]))
-    print(f"{a.chains} chains x {a.iters} iterations, {a.grid}^2: batched replay {t_batched:.2f} s "
+    if a.mode == 'pcg64':
+        same = all(np.array_equal(res[i][4], ser[i][4]) and np.array_equal(res[i][6], ser[i][6], equal_nan=True) and
+                   np.allclose(res[i][0], ser[i][0], rtol=0, atol=1e-8) for i in range(a.serial_chains))
+    how = 'accept masks / blocks identical, beds 1e-8 m' if a.mode == 'pcg64' else 'bit for bit'
+    print(f"{a.chains} chains x {a.iters} iterations, {a.grid}^2: batched {a.mode} {t_batched:.2f} s "
           f"({a.chains * (a.iters - 1) / t_batched:.0f} chain-steps/s); one chain after another {t_serial:.1f} s "
-          f"(extrapolated from {a.serial_chains} chains) -> {t_serial / t_batched:.1f}x; bit-equal on those chains: {same}")
+          f"(extrapolated from {a.serial_chains} chains) -> {t_serial / t_batched:.1f}x; equal on those chains ({how}): {same}")

@@ -1,0 +1,128 @@
+"""-m gpu: gsm_draw_pcg64 -- NumPy's PCG64 generator streams of the reference's chains advanced on the device -- against NumPy
+itself on the host, in the reference's call order (MCMC.py:755, :199-207, :242, :251; :1254-1258, :1336): every draw bit for
+bit, the final generator states included."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_draws(rf, gen_rf, gen_ch, n_steps, H, W, region_mask):
+    out = dict(size_idx=[], centre=[], u=[], sc=[], re=[], im=[], ng=[])
+    for _ in range(n_steps):
+        i = int(gen_rf.integers(low=0, high=rf.pairs.shape[1], size=1)[0])
+        bw, bh = int(rf.pairs[0, i]), int(rf.pairs[1, i])
+        scale = gen_rf.uniform(rf.scale_min, rf.scale_max) / 3.0
+        nug = gen_rf.uniform(0.0, rf.nugget_max)
+        if not rf.isotropic:
+            rx = gen_rf.uniform(rf.range_min_x, rf.range_max_x); ry = gen_rf.uniform(rf.range_min_y, rf.range_max_y)
+        else:
+            rx = ry = gen_rf.uniform(rf.range_min_x, rf.range_max_x)
+        re = gen_rf.normal(size=(bh, bw)); im = gen_rf.normal(size=(bh, bw))
+        ng = gen_rf.normal(0, np.sqrt(nug), size=(bh, bw))
+        while True:
+            ix = int(gen_ch.integers(low=0, high=H, size=1)[0]); iy = int(gen_ch.integers(low=0, high=W, size=1)[0])
+            if region_mask is None or region_mask[ix, iy] == 1:
+                break
+        out["size_idx"].append(i); out["centre"].append((ix, iy)); out["u"].append(gen_ch.random())
+        out["sc"].append((scale, nug, rx, ry)); out["re"].append(re); out["im"].append(im); out["ng"].append(ng)
+    return out
+
+
+@pytest.mark.parametrize("H,blocks,isotropic,nugget_max,in_region", [(64, (8, 16), True, 0.0, True), (96, (20, 40), False, 4.0, True),
+                                                                      (256, (50, 80), True, 0.0, False)])
+def test_device_draws_equal_numpy(H, blocks, isotropic, nugget_max, in_region):
+    from mcmc_gpu_amd import MCMC_gpu, synthetic
+    from mcmc_gpu_amd.engine import GsmEngine
+    prob, ch, _ = synthetic.template(H)
+    rf = MCMC_gpu.RandField(10e3, 50e3, 12e3, 40e3, 50, 150, nugget_max, "Matern", isotropic, smoothness=0.9125)
+    rf.set_block_sizes(blocks[0], blocks[1], blocks[0], blocks[1])
+    rf.set_weight_param(2, 0, 6, 1, 49900.0, prob["resolution"])
+    rf.set_generation_method(True)
+    n_chains, n_steps = 5, 7 if H < 256 else 4
+    eng = ch._make_engine(rf, n_chains, 0)
+    seeds = [3, 7, 2 ** 40 + 11, 123456789, 987654321987654321]
+    gens_rf = [np.random.default_rng(seed=s) for s in seeds]
+    gens_ch = [np.random.default_rng(seed=s) for s in seeds]
+    for g in gens_ch[:2]:
+        g.integers(low=0, high=9, size=1)                      # start with a cached 32-bit half in some generators
+    region = prob["region_mask"] if in_region else None
+    d_rf = torch.as_tensor(GsmEngine.pack_pcg64_states(gens_rf).view(np.int64)).to(eng.dev)
+    d_ch = torch.as_tensor(GsmEngine.pack_pcg64_states(gens_ch).view(np.int64)).to(eng.dev)
+    d_reg = torch.as_tensor(np.ascontiguousarray(region == 1, dtype=np.uint8)).to(eng.dev) if in_region else None
+    d = eng.draw_pcg64(n_steps, rf, d_rf, d_ch, d_reg)
+    torch.cuda.synchronize()
+    st_rf = GsmEngine.unpack_pcg64_states(d_rf.cpu().numpy().view(np.uint64))
+    st_ch = GsmEngine.unpack_pcg64_states(d_ch.cpu().numpy().view(np.uint64))
+    re, im = d["noise_re"].cpu().numpy(), d["noise_im"].cpu().numpy()
+    ng = d["nugget"].cpu().numpy() if d["nugget"] is not None else None
+    assert (ng is None) == (nugget_max == 0.0)
+    for c in range(n_chains):
+        h = _host_draws(rf, gens_rf[c], gens_ch[c], n_steps, H, H, region)
+        assert np.array_equal(d["size_idx"][c].cpu().numpy(), h["size_idx"])
+        assert np.array_equal(d["centre"][c].cpu().numpy(), np.array(h["centre"]))
+        assert np.array_equal(d["u"][c].cpu().numpy(), np.array(h["u"]))
+        assert np.array_equal(d["rf_scalars"][c].cpu().numpy(), np.array(h["sc"]))
+        for s in range(n_steps):
+            B = h["re"][s].size
+            assert np.array_equal(re[c, s, :B], h["re"][s].ravel()), (c, s, "real plane")
+            assert np.array_equal(im[c, s, :B], h["im"][s].ravel()), (c, s, "imaginary plane")
+            if ng is not None:
+                assert np.array_equal(ng[c, s, :B], h["ng"][s].ravel()), (c, s, "nugget plane")
+        assert st_rf[c] == gens_rf[c].bit_generator.state, "RandField generator state"
+        assert st_ch[c] == gens_ch[c].bit_generator.state, "chain generator state"
+    eng.close()
+
+
+def _rehydrate(ch, rf, seed, bed):
+    from copy import deepcopy
+    from mcmc_gpu_amd import MCMC_gpu
+    cp = deepcopy(ch.__dict__); cp["rng_seed"] = seed; cp["initial_bed"] = bed
+    rp = deepcopy(rf.__dict__); rp["rng_seed"] = seed
+    return MCMC_gpu.init_lsc_chain_by_instance(cp), MCMC_gpu.initiate_RF_by_instance(rp)
+
+
+def test_pcg64_mode_follows_the_reference_chain(golden_dir):
+    """chain_crf_gpu.run in 'pcg64' mode on the seeds of golden F1 (the imported reference's chain_crf.run, 300 iterations): the
+    draws are NumPy's, made on the device, so block records, accept mask, resampled counts and the final generator states are
+    the reference's; the bed and the loss follow to the accuracy of the device's inverse DFT against pocketfft (1e-12 x the
+    field scale per proposal, summed over the accepted steps)."""
+    from mcmc_gpu_amd import synthetic
+    g = np.load(golden_dir / "f1_chain64_standard.npz")
+    prob, ch, rf = synthetic.template(64)
+    c, r = _rehydrate(ch, rf, 7, prob["bed"].copy())
+    c.set_rng_mode('pcg64')
+    c.replay_chunk = 64
+    out = c.run(300, r, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None)
+    bed, loss_mc, loss_data, loss, steps, resampled, blocks = out
+    assert np.array_equal(steps, g["steps"]), "accept mask differs from the reference"
+    assert np.array_equal(blocks, g["blocks"], equal_nan=True)
+    assert np.array_equal(resampled, g["resampled"])
+    np.testing.assert_allclose(loss, g["loss"], rtol=1e-10)
+    np.testing.assert_allclose(bed, g["bed"], rtol=0, atol=1e-9)
+    # the generators end where the host-drawn replay chain leaves them
+    c2, r2 = _rehydrate(ch, rf, 7, prob["bed"].copy())
+    c2.replay_chunk = 64
+    c2.run(300, r2, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None)
+    assert c.rng.bit_generator.state == c2.rng.bit_generator.state and r.rng.bit_generator.state == r2.rng.bit_generator.state
+
+
+def test_pcg64_batches_equal_host_replay_at_headline_geometry():
+    """run_many_pcg64 against run_many_replay (host NumPy draws + NumPy FFT, the bit-exact parity mode): 24 chains x 120 steps at
+    256 x 256 with blocks 50-80 -- identical accept masks, blocks and generator states, beds within 1e-9 m."""
+    from mcmc_gpu_amd import MCMC_gpu, synthetic
+    prob, ch, rf = synthetic.template(256)
+    n = 24
+    beds = np.stack(list(synthetic.initial_beds(prob, n)))
+    st = [np.random.default_rng(seed=900 + i).bit_generator.state for i in range(n)]
+    a, rf_a, ch_a = MCMC_gpu.run_many_pcg64(ch, rf, beds, st, st, 121, batch=32)
+    b, rf_b, ch_b = MCMC_gpu.run_many_replay(ch, rf, beds, st, st, 121, n_workers=8)
+    assert rf_a == rf_b and ch_a == ch_b
+    for x, y in zip(a, b):
+        assert np.array_equal(x[4], y[4]) and np.array_equal(x[6], y[6], equal_nan=True) and np.array_equal(x[5], y[5])
+        np.testing.assert_allclose(x[3], y[3], rtol=1e-10)
+        np.testing.assert_allclose(x[0], y[0], rtol=0, atol=1e-9)
+    assert 0.3 < np.mean([x[4][1:].mean() for x in a]) < 0.8
