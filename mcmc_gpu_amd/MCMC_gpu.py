@@ -706,18 +706,24 @@ def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, bat
         d_reg = (torch.as_tensor(np.ascontiguousarray(np.asarray(chain.region_mask) == 1, dtype=np.uint8)).to(dev)
                  if chain.update_in_region else None)
         stride = eng.field_stride
-        if batch is None:      # three noise planes + the fields of a batch: at most ~2 GiB
-            batch = int(max(1, min(256, (2 << 30) // (4 * n_chains * stride * 8))))
+        if batch is None:      # three noise planes + the fields of a batch: at most ~12 GiB
+            batch = int(max(1, min(256, (12 << 30) // (4 * n_chains * stride * 8))))
         batch = max(1, min(int(batch), max(n_steps, 1)))
-        loss = torch.empty((n_chains, max(n_steps, 1)), dtype=torch.float64, device=dev)
-        acc = torch.empty((n_chains, max(n_steps, 1)), dtype=torch.uint8, device=dev)
+        n_al = max(n_steps, 1)
+        loss = torch.empty((n_chains, n_al), dtype=torch.float64, device=dev)
+        acc = torch.empty((n_chains, n_al), dtype=torch.uint8, device=dev)
+        si_all = torch.empty((n_chains, n_al), dtype=torch.int32, device=dev)
         blocks = np.zeros((n_chains, n_steps, 4))
-        fields = torch.zeros((n_chains, batch, stride), dtype=torch.float64, device=dev)
+        ce_all = torch.empty((n_chains, n_al, 2), dtype=torch.int32, device=dev)
+        shape = (n_chains, batch, stride)
+        fields = torch.zeros(shape, dtype=torch.float64, device=dev)
+        planes = (torch.zeros(shape, dtype=torch.float64, device=dev), torch.zeros(shape, dtype=torch.float64, device=dev),
+                  torch.zeros(shape, dtype=torch.float64, device=dev) if p.nugget_max > 0.0 else None)
         t0 = time.time()
         done = 0
         while done < n_steps:
             n = min(batch, n_steps - done)
-            d = eng.draw_pcg64(n, p, d_rf, d_ch, d_reg)
+            d = eng.draw_pcg64(n, p, d_rf, d_ch, d_reg, buffers=planes if n == batch else None)
             fl = fields if n == batch else torch.zeros((n_chains, n, stride), dtype=torch.float64, device=dev)
             l_b = torch.empty((n_chains, n), dtype=torch.float64, device=dev)
             a_b = torch.empty((n_chains, n), dtype=torch.uint8, device=dev)
@@ -730,14 +736,17 @@ def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, bat
                                                   _ptr(l_b), _ptr(a_b), eng._stream()))
             loss[:, done:done + n] = l_b
             acc[:, done:done + n] = a_b
-            si = d['size_idx'].cpu().numpy()
-            blocks[:, done:done + n, 0:2] = d['centre'].cpu().numpy()
-            blocks[:, done:done + n, 2] = eng.bh[si]
-            blocks[:, done:done + n, 3] = eng.bw[si]
+            si_all[:, done:done + n] = d['size_idx']
+            ce_all[:, done:done + n] = d['centre']
             done += n
             if progress:
+                torch.cuda.synchronize(dev)
                 print(f"{n_chains} chains: {100 * done / n_steps:3.0f}% | chain-it/s: {n_chains * done / max(time.time() - t0, 1e-9):9.1f}",
                       file=sys.stdout, flush=True)
+        si = si_all[:, :n_steps].cpu().numpy()
+        blocks[:, :, 0:2] = ce_all[:, :n_steps].cpu().numpy()
+        blocks[:, :, 2] = eng.bh[si]
+        blocks[:, :, 3] = eng.bw[si]
         loss_h = loss[:, :n_steps].cpu().numpy()
         acc_h = acc[:, :n_steps].cpu().numpy()
         rf_out = GsmEngine.unpack_pcg64_states(d_rf.cpu().numpy().view(np.uint64))

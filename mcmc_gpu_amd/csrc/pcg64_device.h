@@ -192,8 +192,18 @@ struct Stream {
       if (lane < L && dst) dst[rank + lane] = loc + scale * x;
       rank += L;
       if (L == m) { advance(m); continue; }
-      // the draw at position L + 1 takes a slow path of random_standard_normal: resolved in uniform code
-      const uint64_t rawL = output_xsl_rr(ahead(L + 1));
+      // the draw at position L + 1 takes a slow path of random_standard_normal: resolved in uniform code.  The draws it
+      // consumes next (positions L + 2, ...) are the ones lanes L + 1, ... hold already: read them across the wave; only past
+      // lane 63 the state is jumped ahead.
+      auto raw_at = [&](int pos1) -> uint64_t {                             // the draw `pos1` positions ahead of `s` (1-based)
+        if (pos1 <= 64) {
+          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(uint32_t)raw, pos1 - 1);
+          const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(uint32_t)(raw >> 32), pos1 - 1);
+          return ((uint64_t)hi << 32) | lo;
+        }
+        return output_xsl_rr(ahead(pos1));
+      };
+      const uint64_t rawL = raw_at(L + 1);
       const int idxL = (int)(rawL & 0xff);
       const uint64_t rL = rawL >> 8;
       const uint64_t rabsL = (rL >> 1) & 0x000fffffffffffffull;
@@ -204,16 +214,25 @@ struct Stream {
       double val = 0.0;
       if (idxL == 0) {
         for (;;) {
-          if (pos + 2 > kJump) { advance(pos); pos = 0; }
-          const double u1 = to_double(output_xsl_rr(ahead(pos + 1)));
-          const double u2 = to_double(output_xsl_rr(ahead(pos + 2)));
+          if (pos + 2 > kJump) break;                                       // (never in practice: > 30 rejected tail pairs in a row)
+          const double u1 = to_double(raw_at(pos + 1));
+          const double u2 = to_double(raw_at(pos + 2));
           pos += 2;
           const double xx = -zinv * log1p_fdlibm(-u1);
           const double yy = -log1p_fdlibm(-u2);
           if (yy + yy > xx * xx) { val = ((rabsL >> 8) & 1) ? -(zr + xx) : zr + xx; produced = true; break; }
         }
+        if (!produced) {                                                    // continue the tail loop from a re-based state
+          advance(pos); pos = 0;
+          for (;;) {
+            const double u1 = next_double(), u2 = next_double();
+            const double xx = -zinv * log1p_fdlibm(-u1);
+            const double yy = -log1p_fdlibm(-u2);
+            if (yy + yy > xx * xx) { val = ((rabsL >> 8) & 1) ? -(zr + xx) : zr + xx; produced = true; break; }
+          }
+        }
       } else {
-        const double uu = to_double(output_xsl_rr(ahead(pos + 1)));
+        const double uu = to_double(raw_at(pos + 1));
         pos += 1;
         const double f0 = __builtin_bit_cast(double, zig[512 + idxL - 1]), f1 = __builtin_bit_cast(double, zig[512 + idxL]);
         if ((f0 - f1) * uu + f1 < exp(-0.5 * xL * xL)) { val = xL; produced = true; }

@@ -307,7 +307,7 @@ class GsmEngine:
         return [{"bit_generator": "PCG64", "state": {"state": int(w[0]) | (int(w[1]) << 64), "inc": int(w[2]) | (int(w[3]) << 64)},
                  "has_uint32": int(w[4]), "uinteger": int(w[5])} for w in np.asarray(words, dtype=np.uint64)]
 
-    def draw_pcg64(self, n_steps, rf, d_rf_state, d_chain_state, d_region_mask=None):
+    def draw_pcg64(self, n_steps, rf, d_rf_state, d_chain_state, d_region_mask=None, buffers=None):
         """n_steps Metropolis steps' worth of the reference's NumPy draws for every chain, on the device.  d_rf_state /
         d_chain_state: int64 device tensors [n_chains, 6] (pack_pcg64_states), advanced in place.  Returns device tensors
         size_idx [n, s], centre [n, s, 2], u [n, s], rf_scalars [n, s, 4], noise_re / noise_im [n, s, field_stride] and
@@ -319,9 +319,12 @@ class GsmEngine:
         u = torch.empty(n, dtype=torch.float64, device=self.dev)
         sc = torch.empty(n * 4, dtype=torch.float64, device=self.dev)
         shape = (self.n_chains, n_steps, self.field_stride)
-        re = torch.zeros(shape, dtype=torch.float64, device=self.dev)
-        im = torch.zeros(shape, dtype=torch.float64, device=self.dev)
-        ng = torch.zeros(shape, dtype=torch.float64, device=self.dev) if p.nugget_max > 0.0 else None
+        if buffers is not None and tuple(buffers[0].shape) == shape:     # caller-owned planes, reused from batch to batch: only the
+            re, im, ng = buffers                                         # bh * bw leading doubles of a record are written and read
+        else:
+            re = torch.zeros(shape, dtype=torch.float64, device=self.dev)
+            im = torch.zeros(shape, dtype=torch.float64, device=self.dev)
+            ng = torch.zeros(shape, dtype=torch.float64, device=self.dev) if p.nugget_max > 0.0 else None
         with torch.cuda.device(self.dev):
             self._check(self.lib.gsm_draw_pcg64(self.h, int(n_steps), C.byref(p), _ptr(d_rf_state), _ptr(d_chain_state),
                                                 _ptr(d_region_mask), _ptr(si), _ptr(ce), _ptr(u), _ptr(sc), _ptr(re), _ptr(im),
