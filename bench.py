@@ -384,6 +384,28 @@ def measure_small_scale(H=64, n_chains=4, n_iter=400, cpu_iters=20):
                                       "cycles per fp64-class instruction; wall time of the whole iteration (8 launches), not of the kernel alone"}}}
 
 
+def measure_pcg64_mode(H=256, n_chains=1024, n_steps=256):
+    """The headline geometry in the 'pcg64' draw mode: the reference's two NumPy PCG64 generator streams per chain advanced on the
+    device bit for bit (gsm_draw_pcg64), device spectral synthesis, replay step kernel -- the reference-faithful chain without
+    host draws.  Wall time of MCMC_gpu.run_many_pcg64 incl. engine setup and the upload / download of the beds."""
+    import numpy as np
+    from mcmc_gpu_amd import MCMC_gpu, synthetic
+    prob, ch, rf = synthetic.template(H)
+    beds = np.stack(list(synthetic.initial_beds(prob, n_chains)))
+    st = [np.random.default_rng(seed=7 + i).bit_generator.state for i in range(n_chains)]
+    MCMC_gpu.run_many_pcg64(ch, rf, beds[:8], st[:8], st[:8], 9)                    # warm-up
+    t0 = time.perf_counter()
+    out, _, _ = MCMC_gpu.run_many_pcg64(ch, rf, beds, st, st, n_steps + 1)
+    dt = time.perf_counter() - t0
+    return {"metric": f"chain-steps/sec on {H}x{H} grid x {n_chains} chains in the 'pcg64' draw mode",
+            "value": n_chains * n_steps / dt, "unit": "chain-steps/s", "n_gpus": 1, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"largeScaleChain {H}x{H} grid, {n_chains} chains, fp64, NumPy PCG64 streams of the reference advanced on the "
+                                   "device (draws, block records, accept masks and generator states of the CPU reference on the same seeds), "
+                                   "blocks 50-80, sigma_mc 5", "steps": n_steps},
+            "accept_rate": float(np.mean([o[4][1:].mean() for o in out])), "timed_seconds": dt,
+            "note": "host-drawn replay mode on the same box: 25-41 k chain-steps/s with 15 draw workers (scripts/replay_batch_bench.py)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -462,6 +484,13 @@ def main():
             except Exception as e:      # the headline line must not be lost to a failure here; the failure is reported
                 extras[name] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        try:
+            extras["configs[1] in the pcg64 draw mode"] = measure_pcg64_mode()
+            extras["configs[1] in the pcg64 draw mode"]["wall_seconds_incl_setup"] = time.perf_counter() - t0
+        except Exception as e:
+            extras["configs[1] in the pcg64 draw mode"] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
         t0 = time.perf_counter()
         try:
             extras["configs[0] on the device"] = measure_small_scale(cpu_iters=0 if args.no_cpu_baseline else 20)

@@ -173,75 +173,102 @@ struct Stream {
     return (uint32_t)(m >> 32);
   }
 
+  // the state `n` draws ahead of `s`, 1 <= n <= 64, from the lanes' states of the current window (lane n - 1 holds it)
+  static __device__ __forceinline__ u128 lane_state(u128 st, int n) {
+    u128 r;
+    r.lo = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)st.lo, n - 1) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(st.lo >> 32), n - 1) << 32);
+    r.hi = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)st.hi, n - 1) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(st.hi >> 32), n - 1) << 32);
+    return r;
+  }
+
   // `count` values loc + scale * standard_normal() in stream order to dst[0 .. count) (dst may be nullptr: draws consumed,
   // nothing stored).  Called by all 64 lanes of the wavefront; A_l / C_l: this lane's jump constants (mult^(l+1), inc * G_(l+1)).
+  //
+  // A window = the next 64 draws, one per lane.  random_standard_normal consumes ONE draw per normal on its fast path (99.3 %),
+  // TWO on the wedge path (the draw itself and a uniform; the normal is produced or not) and 2 k + 1 in the tail (idx == 0).  So
+  // inside a window the positions that START a normal follow from the lanes' own decodes: every position is a start unless it is
+  // the uniform of a wedge start before it.  All starts of a window -- fast and wedge alike -- are resolved in ONE pass (the wedge
+  // test in vector code under its lanes' EXEC), ranks by a prefix count over the ballot of produced normals; the window is cut
+  // before a tail start (resolved in uniform code at the head of the next window) and before a wedge start in lane 63 (its
+  // uniform is the next window's draw).  The state behind the consumed draws is the one a lane already holds (v_readlane).
   __device__ __forceinline__ void normals(int count, double loc, double scale, double* dst, int lane, u128 A_l, u128 C_l) {
     const double zr = 3.6541528853610087963519472518, zinv = 0.27366123732975827203338247596;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int rank = 0;
     while (rank < count) {
-      const uint64_t raw = output_xsl_rr(add128(mul128(A_l, s), C_l));      // the draw lane + 1 positions ahead
+      const u128 st = add128(mul128(A_l, s), C_l);                          // the state lane + 1 draws ahead
+      const uint64_t raw = output_xsl_rr(st);
       const int idx = (int)(raw & 0xff);
       const uint64_t r8 = raw >> 8;
       const uint64_t rabs = (r8 >> 1) & 0x000fffffffffffffull;
       double x = (double)rabs * __builtin_bit_cast(double, zig[256 + idx]);
       if (r8 & 1) x = -x;
-      const int m = min(64, count - rank);
-      const bool slow = !(rabs < zig[idx]) && lane < m;
-      const unsigned long long sm = __ballot(slow);
-      const int L = sm ? (__ffsll((long long)sm) - 1) : m;                  // draws ahead of the first slow one: all fast
-      if (lane < L && dst) dst[rank + lane] = loc + scale * x;
-      rank += L;
-      if (L == m) { advance(m); continue; }
-      // the draw at position L + 1 takes a slow path of random_standard_normal: resolved in uniform code.  The draws it
-      // consumes next (positions L + 2, ...) are the ones lanes L + 1, ... hold already: read them across the wave; only past
-      // lane 63 the state is jumped ahead.
-      auto raw_at = [&](int pos1) -> uint64_t {                             // the draw `pos1` positions ahead of `s` (1-based)
-        if (pos1 <= 64) {
-          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(uint32_t)raw, pos1 - 1);
-          const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(uint32_t)(raw >> 32), pos1 - 1);
-          return ((uint64_t)hi << 32) | lo;
-        }
-        return output_xsl_rr(ahead(pos1));
-      };
-      const uint64_t rawL = raw_at(L + 1);
-      const int idxL = (int)(rawL & 0xff);
-      const uint64_t rL = rawL >> 8;
-      const uint64_t rabsL = (rL >> 1) & 0x000fffffffffffffull;
-      double xL = (double)rabsL * __builtin_bit_cast(double, zig[256 + idxL]);
-      if (rL & 1) xL = -xL;
-      int pos = L + 1;                                                      // draws consumed so far, counted from `s`
-      bool produced = false;
-      double val = 0.0;
-      if (idxL == 0) {
-        for (;;) {
-          if (pos + 2 > kJump) break;                                       // (never in practice: > 30 rejected tail pairs in a row)
-          const double u1 = to_double(raw_at(pos + 1));
-          const double u2 = to_double(raw_at(pos + 2));
+      const bool slow = !(rabs < zig[idx]);
+      const unsigned long long slow_mask = __ballot(slow), tail_mask = __ballot(slow && idx == 0);
+      if (tail_mask & 1ull) {
+        // ---- the window begins with a tail start: uniform code (about 1 normal in 3 700) -------------------------------
+        auto raw_at = [&](int pos1) -> uint64_t {                           // the draw pos1 positions ahead of `s` (1 .. 64)
+          return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)raw, pos1 - 1) |
+                 ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(raw >> 32), pos1 - 1) << 32);
+        };
+        const uint64_t raw0 = raw_at(1);
+        const uint64_t rabs0 = ((raw0 >> 8) >> 1) & 0x000fffffffffffffull;
+        int pos = 1;
+        double val = 0.0;
+        bool produced = false;
+        while (pos + 2 <= 64) {
+          const double u1 = to_double(raw_at(pos + 1)), u2 = to_double(raw_at(pos + 2));
           pos += 2;
           const double xx = -zinv * log1p_fdlibm(-u1);
           const double yy = -log1p_fdlibm(-u2);
-          if (yy + yy > xx * xx) { val = ((rabsL >> 8) & 1) ? -(zr + xx) : zr + xx; produced = true; break; }
+          if (yy + yy > xx * xx) { val = ((rabs0 >> 8) & 1) ? -(zr + xx) : zr + xx; produced = true; break; }
         }
-        if (!produced) {                                                    // continue the tail loop from a re-based state
-          advance(pos); pos = 0;
-          for (;;) {
-            const double u1 = next_double(), u2 = next_double();
-            const double xx = -zinv * log1p_fdlibm(-u1);
-            const double yy = -log1p_fdlibm(-u2);
-            if (yy + yy > xx * xx) { val = ((rabsL >> 8) & 1) ? -(zr + xx) : zr + xx; produced = true; break; }
-          }
+        s = lane_state(st, pos);
+        while (!produced) {                                                 // > 31 rejected pairs in a row: never in practice
+          const double u1 = next_double(), u2 = next_double();
+          const double xx = -zinv * log1p_fdlibm(-u1);
+          const double yy = -log1p_fdlibm(-u2);
+          if (yy + yy > xx * xx) { val = ((rabs0 >> 8) & 1) ? -(zr + xx) : zr + xx; produced = true; }
         }
-      } else {
-        const double uu = to_double(raw_at(pos + 1));
-        pos += 1;
-        const double f0 = __builtin_bit_cast(double, zig[512 + idxL - 1]), f1 = __builtin_bit_cast(double, zig[512 + idxL]);
-        if ((f0 - f1) * uu + f1 < exp(-0.5 * xL * xL)) { val = xL; produced = true; }
-      }
-      if (produced) {
         if (lane == 0 && dst) dst[rank] = loc + scale * val;
         rank += 1;
+        continue;
       }
-      if (pos > 0) advance(pos);
+      // ---- starts of the window ---------------------------------------------------------------------------------------
+      unsigned long long start_mask = ~0ull;
+      for (unsigned long long t = slow_mask & ~tail_mask; t; t &= t - 1) {  // wedge positions in ascending order
+        const int bpos = __ffsll((long long)t) - 1;
+        if (((start_mask >> bpos) & 1ull) && bpos < 63) start_mask &= ~(1ull << (bpos + 1));   // its uniform is not a start
+      }
+      const unsigned long long wedge63 = (slow_mask & ~tail_mask) & start_mask & (1ull << 63);
+      const unsigned long long cut = (tail_mask & start_mask) | wedge63;
+      const int limit = cut ? (__ffsll((long long)cut) - 1) : 64;           // >= 1: lane 0 is a start and neither cut case
+      const bool is_start = ((start_mask >> lane) & 1ull) && lane < limit;
+      // the uniform of a wedge start is the next lane's draw
+      const uint64_t raw_next = (uint64_t)(uint32_t)__shfl_down((int)(uint32_t)raw, 1, 64) |
+                                ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(raw >> 32), 1, 64) << 32);
+      bool produced = is_start && !slow;
+      if (is_start && slow) {
+        const double f0 = __builtin_bit_cast(double, zig[512 + idx - 1]), f1 = __builtin_bit_cast(double, zig[512 + idx]);
+        produced = (f0 - f1) * to_double(raw_next) + f1 < exp(-0.5 * x * x);
+      }
+      const unsigned long long pmask = __ballot(produced);
+      const int need = count - rank, got = __popcll(pmask);
+      const int my = __popcll(pmask & below);
+      if (produced && my < need && dst) dst[rank + my] = loc + scale * x;
+      int consumed = limit;
+      if (got >= need) {                                                    // the plane ends inside (or at the end of) the window
+        // lane of the need-th produced normal; the draws up to it (and its uniform, if it is a wedge start) are consumed --
+        // nothing behind it, not even a rejected wedge start: NumPy stops drawing with the last normal of the array
+        unsigned long long t = pmask;
+        for (int k = 1; k < need; ++k) t &= t - 1;
+        const int q = __ffsll((long long)t) - 1;
+        consumed = q + 1 + (int)((slow_mask >> q) & 1ull);
+      }
+      rank += min(got, need);
+      s = lane_state(st, consumed);
     }
   }
 };
