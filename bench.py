@@ -384,7 +384,7 @@ def measure_small_scale(H=64, n_chains=4, n_iter=400, cpu_iters=20):
                                       "cycles per fp64-class instruction; wall time of the whole iteration (8 launches), not of the kernel alone"}}}
 
 
-def measure_pcg64_mode(H=256, n_chains=1024, n_steps=256):
+def measure_pcg64_mode(H=256, n_chains=1024, n_steps=2048):
     """The headline geometry in the 'pcg64' draw mode: the reference's two NumPy PCG64 generator streams per chain advanced on the
     device bit for bit (gsm_draw_pcg64), device spectral synthesis, replay step kernel -- the reference-faithful chain without
     host draws.  Wall time of MCMC_gpu.run_many_pcg64 incl. engine setup and the upload / download of the beds."""

@@ -162,7 +162,7 @@ int gsm_propose_philox(gsm_handle h, int32_t n_steps, int64_t step0, const uint6
  * MCMC.py:242 and :251, row-major (bh, bw) (nugget_field may be NULL when rf->nugget_max == 0: the draws are consumed, nothing is
  * stored), centre[2 r] (row, col) and u[r] (MCMC.py:1336).  Feed them to gsm_spectral_from_noise and gsm_run_replay: the chain
  * then follows the CPU reference on the same seeds -- accept masks identical, beds / losses to the 1e-12 x scale of the device's
- * inverse DFT against pocketfft -- without any host draw.  Synchronises the stream.
+ * inverse DFT against pocketfft -- without any host draw.  Asynchronous on `stream`.
  * Replaces: the numpy.random calls of RandField.get_rfblock / spectral_synthesis_field / chain_crf.run listed above. */
 int gsm_draw_pcg64(gsm_handle h, int32_t n_steps, const gsm_rf_params* rf, uint64_t* rf_state, uint64_t* chain_state,
                    const uint8_t* region_mask, int32_t* size_idx, int32_t* centre, double* u, double* rf_scalars,

@@ -706,8 +706,8 @@ def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, bat
         d_reg = (torch.as_tensor(np.ascontiguousarray(np.asarray(chain.region_mask) == 1, dtype=np.uint8)).to(dev)
                  if chain.update_in_region else None)
         stride = eng.field_stride
-        if batch is None:      # three noise planes + the fields of a batch: at most ~12 GiB
-            batch = int(max(1, min(256, (12 << 30) // (4 * n_chains * stride * 8))))
+        if batch is None:      # two sets of three noise planes + the fields of a batch: at most ~16 GiB
+            batch = int(max(1, min(256, (16 << 30) // (7 * n_chains * stride * 8))))
         batch = max(1, min(int(batch), max(n_steps, 1)))
         n_al = max(n_steps, 1)
         loss = torch.empty((n_chains, n_al), dtype=torch.float64, device=dev)
@@ -715,34 +715,57 @@ def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, bat
         si_all = torch.empty((n_chains, n_al), dtype=torch.int32, device=dev)
         blocks = np.zeros((n_chains, n_steps, 4))
         ce_all = torch.empty((n_chains, n_al, 2), dtype=torch.int32, device=dev)
-        shape = (n_chains, batch, stride)
-        fields = torch.zeros(shape, dtype=torch.float64, device=dev)
-        planes = (torch.zeros(shape, dtype=torch.float64, device=dev), torch.zeros(shape, dtype=torch.float64, device=dev),
-                  torch.zeros(shape, dtype=torch.float64, device=dev) if p.nugget_max > 0.0 else None)
+        fields = torch.zeros((n_chains, batch, stride), dtype=torch.float64, device=dev)
+        nug = p.nugget_max > 0.0
+        bufs = [eng.alloc_pcg64_buffers(batch, nug), eng.alloc_pcg64_buffers(batch, nug)]
+        # Two streams: the draws of batch k + 1 (one wavefront per chain: latency-bound, leaves most of the chip idle) run beside the
+        # spectral synthesis and the steps of batch k.  Events order the reuse of the two draw buffers.
+        s_draw, s_step = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        cur = torch.cuda.current_stream(dev)
+        s_draw.wait_stream(cur); s_step.wait_stream(cur)
+        ev_drawn = [torch.cuda.Event(), torch.cuda.Event()]
+        ev_free = [None, None]
+        sizes = [min(batch, n_steps - lo) for lo in range(0, n_steps, batch)]
+
+        def draw(k):
+            with torch.cuda.stream(s_draw):
+                if ev_free[k & 1] is not None:
+                    s_draw.wait_event(ev_free[k & 1])
+                n = sizes[k]
+                d = eng.draw_pcg64(n, p, d_rf, d_ch, d_reg, buffers=bufs[k & 1] if n == batch else None)
+                ev_drawn[k & 1].record(s_draw)
+            return d
+
         t0 = time.time()
         done = 0
-        while done < n_steps:
-            n = min(batch, n_steps - done)
-            d = eng.draw_pcg64(n, p, d_rf, d_ch, d_reg, buffers=planes if n == batch else None)
-            fl = fields if n == batch else torch.zeros((n_chains, n, stride), dtype=torch.float64, device=dev)
-            l_b = torch.empty((n_chains, n), dtype=torch.float64, device=dev)
-            a_b = torch.empty((n_chains, n), dtype=torch.uint8, device=dev)
-            with torch.cuda.device(dev):
+        nxt = draw(0) if sizes else None
+        for k, n in enumerate(sizes):
+            d = nxt
+            nxt = draw(k + 1) if k + 1 < len(sizes) else None
+            with torch.cuda.stream(s_step):
+                s_step.wait_event(ev_drawn[k & 1])
+                fl = fields if n == batch else torch.zeros((n_chains, n, stride), dtype=torch.float64, device=dev)
+                l_b = torch.empty((n_chains, n), dtype=torch.float64, device=dev)
+                a_b = torch.empty((n_chains, n), dtype=torch.uint8, device=dev)
                 eng._check(eng.lib.gsm_spectral_from_noise(eng.h, n_chains * n, _ptr(d['size_idx']), _ptr(d['rf_scalars']), C.byref(p),
                                                            _ptr(d['noise_re']), _ptr(d['noise_im']), _ptr(d['nugget']), _ptr(fl), stride,
                                                            eng._stream()))
                 eng._check(eng.lib.gsm_run_replay(eng.h, n, _ptr(eng.beds), _ptr(eng.energy), _ptr(eng.resampled), _ptr(eng.loss_sum),
                                                   _ptr(d['size_idx']), _ptr(d['centre']), _ptr(d['u']), _ptr(fl), stride,
                                                   _ptr(l_b), _ptr(a_b), eng._stream()))
-            loss[:, done:done + n] = l_b
-            acc[:, done:done + n] = a_b
-            si_all[:, done:done + n] = d['size_idx']
-            ce_all[:, done:done + n] = d['centre']
+                loss[:, done:done + n] = l_b
+                acc[:, done:done + n] = a_b
+                si_all[:, done:done + n] = d['size_idx']
+                ce_all[:, done:done + n] = d['centre']
+                ev_free[k & 1] = torch.cuda.Event()
+                ev_free[k & 1].record(s_step)
             done += n
             if progress:
-                torch.cuda.synchronize(dev)
+                s_step.synchronize()
                 print(f"{n_chains} chains: {100 * done / n_steps:3.0f}% | chain-it/s: {n_chains * done / max(time.time() - t0, 1e-9):9.1f}",
                       file=sys.stdout, flush=True)
+        cur.wait_stream(s_draw); cur.wait_stream(s_step)
+        torch.cuda.synchronize(dev)
         si = si_all[:, :n_steps].cpu().numpy()
         blocks[:, :, 0:2] = ce_all[:, :n_steps].cpu().numpy()
         blocks[:, :, 2] = eng.bh[si]

@@ -307,30 +307,30 @@ class GsmEngine:
         return [{"bit_generator": "PCG64", "state": {"state": int(w[0]) | (int(w[1]) << 64), "inc": int(w[2]) | (int(w[3]) << 64)},
                  "has_uint32": int(w[4]), "uinteger": int(w[5])} for w in np.asarray(words, dtype=np.uint64)]
 
-    def draw_pcg64(self, n_steps, rf, d_rf_state, d_chain_state, d_region_mask=None, buffers=None):
-        """n_steps Metropolis steps' worth of the reference's NumPy draws for every chain, on the device.  d_rf_state /
-        d_chain_state: int64 device tensors [n_chains, 6] (pack_pcg64_states), advanced in place.  Returns device tensors
-        size_idx [n, s], centre [n, s, 2], u [n, s], rf_scalars [n, s, 4], noise_re / noise_im [n, s, field_stride] and
-        nugget (or None)."""
-        p = rf if isinstance(rf, RfParams) else self.rf_struct(rf)
+    def alloc_pcg64_buffers(self, n_steps, nugget):
+        """Caller-owned outputs of draw_pcg64 for batches of n_steps (reused from batch to batch: only the bh * bw leading doubles of
+        a record's planes are written and read)."""
         n = self.n_chains * n_steps
-        si = torch.empty(n, dtype=torch.int32, device=self.dev)
-        ce = torch.empty(n * 2, dtype=torch.int32, device=self.dev)
-        u = torch.empty(n, dtype=torch.float64, device=self.dev)
-        sc = torch.empty(n * 4, dtype=torch.float64, device=self.dev)
         shape = (self.n_chains, n_steps, self.field_stride)
-        if buffers is not None and tuple(buffers[0].shape) == shape:     # caller-owned planes, reused from batch to batch: only the
-            re, im, ng = buffers                                         # bh * bw leading doubles of a record are written and read
-        else:
-            re = torch.zeros(shape, dtype=torch.float64, device=self.dev)
-            im = torch.zeros(shape, dtype=torch.float64, device=self.dev)
-            ng = torch.zeros(shape, dtype=torch.float64, device=self.dev) if p.nugget_max > 0.0 else None
+        z = lambda: torch.zeros(shape, dtype=torch.float64, device=self.dev)
+        return dict(size_idx=torch.empty(n, dtype=torch.int32, device=self.dev), centre=torch.empty(n * 2, dtype=torch.int32, device=self.dev),
+                    u=torch.empty(n, dtype=torch.float64, device=self.dev), rf_scalars=torch.empty(n * 4, dtype=torch.float64, device=self.dev),
+                    noise_re=z(), noise_im=z(), nugget=z() if nugget else None, n_steps=n_steps)
+
+    def draw_pcg64(self, n_steps, rf, d_rf_state, d_chain_state, d_region_mask=None, buffers=None):
+        """n_steps Metropolis steps' worth of the reference's NumPy draws for every chain, on the device (asynchronous on the
+        current stream).  d_rf_state / d_chain_state: int64 device tensors [n_chains, 6] (pack_pcg64_states), advanced in place.
+        Returns device tensors size_idx [n, s], centre [n, s, 2], u [n, s], rf_scalars [n, s, 4], noise_re / noise_im
+        [n, s, field_stride] and nugget (or None); `buffers` (alloc_pcg64_buffers of the same n_steps) are used if given."""
+        p = rf if isinstance(rf, RfParams) else self.rf_struct(rf)
+        b = buffers if (buffers is not None and buffers["n_steps"] == n_steps) else self.alloc_pcg64_buffers(n_steps, p.nugget_max > 0.0)
         with torch.cuda.device(self.dev):
             self._check(self.lib.gsm_draw_pcg64(self.h, int(n_steps), C.byref(p), _ptr(d_rf_state), _ptr(d_chain_state),
-                                                _ptr(d_region_mask), _ptr(si), _ptr(ce), _ptr(u), _ptr(sc), _ptr(re), _ptr(im),
-                                                _ptr(ng), self.field_stride, self._stream()))
-        return dict(size_idx=si.view(self.n_chains, n_steps), centre=ce.view(self.n_chains, n_steps, 2),
-                    u=u.view(self.n_chains, n_steps), rf_scalars=sc.view(self.n_chains, n_steps, 4), noise_re=re, noise_im=im, nugget=ng)
+                                                _ptr(d_region_mask), _ptr(b["size_idx"]), _ptr(b["centre"]), _ptr(b["u"]), _ptr(b["rf_scalars"]),
+                                                _ptr(b["noise_re"]), _ptr(b["noise_im"]), _ptr(b["nugget"]), self.field_stride, self._stream()))
+        return dict(size_idx=b["size_idx"].view(self.n_chains, n_steps), centre=b["centre"].view(self.n_chains, n_steps, 2),
+                    u=b["u"].view(self.n_chains, n_steps), rf_scalars=b["rf_scalars"].view(self.n_chains, n_steps, 4),
+                    noise_re=b["noise_re"], noise_im=b["noise_im"], nugget=b["nugget"])
 
     def enable_timing(self, on=True):
         self._check(self.lib.gsm_enable_timing(self.h, 1 if on else 0))
