@@ -304,6 +304,18 @@ int gsm_sgs_draw_philox(gsm_handle h, const uint64_t* seeds, int64_t iter0, int3
                         int32_t* windows, int32_t* blocks, int32_t* cell_off, int32_t* cell_cnt, int32_t* cells, double* z, double* u,
                         void* stream);
 
+/* gsm_sgs_draw_philox's outputs from the chains' OWN NumPy generators ('pcg64' draw mode of the small-scale chain): chain_state
+ * [dev, n_chains*6] (state lo, hi, inc lo, hi, has_uint32, uinteger of numpy's PCG64 bit_generator.state; in/out) is advanced by
+ * n_iters iterations' worth of draws in chain_sgs.run's order -- integers(0, H), integers(0, W) until region_mask == 1 and
+ * integers(min_x, max_x), integers(min_y, max_y) (MCMC.py:1750-1757), rng.shuffle of the block's (row, col) list (:128: Fisher-Yates
+ * from the back, random_interval's masked rejection on 32-bit words), one rng.normal per cell without conditioning data in
+ * visiting order (:165), rng.random() (:1797) -- bit for bit what NumPy returns (mcmc_gpu_amd/csrc/pcg64_device.h).  Record
+ * r = j * n_chains + c for the j-th iteration; layouts as in gsm_sgs_draw_philox.  Asynchronous; device-side errors are reported
+ * by gsm_sgs_check. */
+int gsm_sgs_draw_pcg64(gsm_handle h, uint64_t* chain_state, int32_t n_iters, const uint8_t* region_mask, const uint8_t* is_data,
+                       int32_t min_x, int32_t max_x, int32_t min_y, int32_t max_y, int32_t max_cells, int32_t* windows,
+                       int32_t* blocks, int32_t* cell_off, int32_t* cell_cnt, int32_t* cells, double* z, double* u, void* stream);
+
 /* Loss and thickness guard of proposed beds over the whole grid: loss[c] = nansum(residual(bed_c + trend)^2 where
  * mc_mask == 1) / (2 sigma^2), bad[c] = number of cells with update_mask == 1 (set it to grounded_ice_mask) and
  * surf - (bed_c + trend) <= 0.  beds [dev, n_chains*H*W], trend [dev, H*W] or NULL, loss [dev, n_chains], bad [dev, n_chains].

@@ -203,6 +203,7 @@ def load() -> C.CDLL:
     lib.gsm_sgs_state_init.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.gsm_sgs_finish.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.gsm_sgs_draw_philox.argtypes = [vp, vp, i64, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsm_sgs_draw_pcg64.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsm_qt_transform.argtypes = [vp, vp, vp, i32, vp, vp, i64, i32, vp]
     lib.gsm_sgs_commit_map.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.gsm_sgs_decide.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]

@@ -775,6 +775,17 @@ extern "C" int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* co
   return GSM_OK;
 }
 
+static int ensure_pcg_tables(gsm_handle h) {
+  if (h->d_pcg_tab) return GSM_OK;
+  std::vector<uint64_t> tab(4 * 128 + 768);
+  const uint64_t* zig = nullptr;
+  pcg64_host_tables(tab.data(), &zig);
+  memcpy(tab.data() + 512, zig, 768 * sizeof(uint64_t));
+  HIPCHK(h, hipMalloc(&h->d_pcg_tab, tab.size() * sizeof(uint64_t)));
+  HIPCHK(h, hipMemcpy(h->d_pcg_tab, tab.data(), tab.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  return GSM_OK;
+}
+
 extern "C" int gsm_draw_pcg64(gsm_handle h, int32_t n_steps, const gsm_rf_params* rf, uint64_t* rf_state, uint64_t* chain_state,
                               const uint8_t* region_mask, int32_t* size_idx, int32_t* centre, double* u, double* rf_scalars,
                               double* noise_re, double* noise_im, double* nugget_field, int64_t field_stride, void* stream) {
@@ -788,14 +799,7 @@ extern "C" int gsm_draw_pcg64(gsm_handle h, int32_t n_steps, const gsm_rf_params
   if (h->B.n_sizes < 1 || (int64_t)h->H >= 0xFFFFFFFFll) return fail(h, GSM_E_ARG, "gsm_draw_pcg64: bad block table / grid");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(h, hipSetDevice(h->device));
-  if (!h->d_pcg_tab) {
-    std::vector<uint64_t> tab(4 * 128 + 768);
-    const uint64_t* zig = nullptr;
-    pcg64_host_tables(tab.data(), &zig);
-    memcpy(tab.data() + 512, zig, 768 * sizeof(uint64_t));
-    HIPCHK(h, hipMalloc(&h->d_pcg_tab, tab.size() * sizeof(uint64_t)));
-    HIPCHK(h, hipMemcpy(h->d_pcg_tab, tab.data(), tab.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-  }
+  { int rc = ensure_pcg_tables(h); if (rc) return rc; }
   PcgDrawArgs a{};
   a.H = h->H; a.W = h->W; a.n_chains = h->n_chains; a.n_steps = n_steps; a.n_sizes = h->B.n_sizes; a.rf = *rf;
   a.bh = h->B.bh; a.bw = h->B.bw; a.rf_state = rf_state; a.ch_state = chain_state; a.region_mask = region_mask;
@@ -920,6 +924,28 @@ extern "C" int gsm_sgs_draw_philox(gsm_handle h, const uint64_t* seeds, int64_t 
   a.max_cells = max_cells; a.mathtab = h->d_mathtab;
   a.win = windows; a.blk = blocks; a.cell_off = cell_off; a.cell_cnt = cell_cnt; a.cells = cells; a.z = z; a.u = u; a.err = h->d_err;
   HIPCHK(h, launch_sgs_draw(a, (hipStream_t)stream));
+  return GSM_OK;
+}
+
+extern "C" int gsm_sgs_draw_pcg64(gsm_handle h, uint64_t* chain_state, int32_t n_iters, const uint8_t* region_mask,
+                                  const uint8_t* is_data, int32_t min_x, int32_t max_x, int32_t min_y, int32_t max_y, int32_t max_cells,
+                                  int32_t* windows, int32_t* blocks, int32_t* cell_off, int32_t* cell_cnt, int32_t* cells, double* z,
+                                  double* u, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!chain_state || !is_data || !windows || !blocks || !cell_off || !cell_cnt || !cells || !z || !u)
+    return fail(h, GSM_E_ARG, "gsm_sgs_draw_pcg64: NULL pointer");
+  if (n_iters < 1 || n_iters > 65535) return fail(h, GSM_E_ARG, "gsm_sgs_draw_pcg64: n_iters must be in [1, 65535]");
+  if (min_x < 1 || max_x <= min_x || min_y < 1 || max_y <= min_y) return fail(h, GSM_E_ARG, "gsm_sgs_draw_pcg64: block size ranges must be 1 <= min < max");
+  if (max_cells < (max_x - 1) * (max_y - 1) || max_cells > 1024) return fail(h, GSM_E_ARG, "gsm_sgs_draw_pcg64: max_cells must hold the largest block and be <= 1024");
+  if (h->H > 65535 || h->W > 65535) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_draw_pcg64: grid sides up to 65535");
+  HIPCHK(h, hipSetDevice(h->device));
+  { int rc = ensure_pcg_tables(h); if (rc) return rc; }
+  SgsDrawArgs a{};
+  a.H = h->H; a.W = h->W; a.n_chains = h->n_chains; a.n_iters = n_iters; a.iter0 = 0; a.seeds = nullptr;
+  a.region_mask = region_mask; a.is_data = is_data; a.min_x = min_x; a.max_x = max_x; a.min_y = min_y; a.max_y = max_y;
+  a.max_cells = max_cells; a.mathtab = nullptr;
+  a.win = windows; a.blk = blocks; a.cell_off = cell_off; a.cell_cnt = cell_cnt; a.cells = cells; a.z = z; a.u = u; a.err = h->d_err;
+  HIPCHK(h, launch_sgs_draw_pcg64(a, chain_state, h->d_pcg_tab, h->d_pcg_tab + 512, (hipStream_t)stream));
   return GSM_OK;
 }
 

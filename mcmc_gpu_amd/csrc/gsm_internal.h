@@ -161,6 +161,8 @@ struct PcgDrawArgs {
 };
 hipError_t launch_pcg64_draw(const PcgDrawArgs& a, hipStream_t st);
 void pcg64_host_tables(uint64_t* jump_out, const uint64_t** zig_out);
+struct SgsDrawArgs;
+hipError_t launch_sgs_draw_pcg64(const SgsDrawArgs& a, uint64_t* states, const uint64_t* jump, const uint64_t* zig, hipStream_t st);
 
 // small-scale chain: sequential Gaussian simulation of one block per chain (sgs_kernel.hip)
 struct SgsCellHdr {          // one per (chain, cell slot), written by sgs_weights_kernel

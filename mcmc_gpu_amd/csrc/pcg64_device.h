@@ -173,6 +173,18 @@ struct Stream {
     return (uint32_t)(m >> 32);
   }
 
+  // Generator.integers(low, high, size=1)[0]
+  __device__ __forceinline__ int integers(int low, int high) { return low + (int)bounded((uint32_t)(high - low)); }
+  // random_interval: uniform on [0, mx] by masked rejection on 32-bit words (Generator.shuffle's index draw)
+  __device__ __forceinline__ uint32_t interval(uint32_t mx) {
+    if (mx == 0) return 0;
+    uint32_t mask = mx;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    uint32_t v;
+    do { v = next32() & mask; } while (v > mx);
+    return v;
+  }
+
   // the state `n` draws ahead of `s`, 1 <= n <= 64, from the lanes' states of the current window (lane n - 1 holds it)
   static __device__ __forceinline__ u128 lane_state(u128 st, int n) {
     u128 r;

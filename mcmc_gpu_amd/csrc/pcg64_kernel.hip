@@ -69,6 +69,89 @@ hipError_t launch_pcg64_draw(const PcgDrawArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// gsm_sgs_draw_pcg64: the draws of the small-scale chain from the chain's own NumPy generator, on the device (one wavefront per
+// chain, iterations one after the other: the stream is sequential).  Per iteration, in the reference's order (MCMC.py:1750-1757
+// block centre with rejection on region_mask and block sizes; :128 rng.shuffle of the block's cells; :165 one rng.normal per cell
+// without conditioning data, in visiting order; :1797 rng.random()).  Same outputs as sgs_draw_kernel (Philox mode).
+__global__ __launch_bounds__(64) void sgs_draw_pcg64_kernel(const SgsDrawArgs a, uint64_t* states, const uint64_t* jump_g, const uint64_t* zig_g) {
+  __shared__ uint64_t jump[4 * pcg::kJump];
+  __shared__ uint64_t zig[kZigTabWords];
+  __shared__ int32_t order[1024];                // packed (row << 16 | col) of the block's cells, shuffled in place
+  __shared__ double zt[1024];                    // the iteration's normals in drawing order
+  const int lane = threadIdx.x, chain = blockIdx.x;
+  for (int i = lane; i < 4 * pcg::kJump; i += 64) jump[i] = jump_g[i];
+  for (int i = lane; i < kZigTabWords; i += 64) zig[i] = zig_g[i];
+  __syncthreads();
+  pcg::Stream G;
+  uint64_t* gs = states + 6 * (size_t)chain;
+  G.s = pcg::u128{gs[0], gs[1]}; G.inc = pcg::u128{gs[2], gs[3]}; G.has32 = (uint32_t)gs[4]; G.cached = (uint32_t)gs[5];
+  G.jump = jump; G.zig = zig;
+  const pcg::u128 A_l{jump[4 * lane], jump[4 * lane + 1]};
+  const pcg::u128 C_l = pcg::mul128(pcg::u128{jump[4 * lane + 2], jump[4 * lane + 3]}, G.inc);
+  for (int j = 0; j < a.n_iters; ++j) {
+    const int64_t rec = (int64_t)j * a.n_chains + chain;
+    int row = 0, col = 0;
+    for (int tries = 0;; ++tries) {
+      row = G.integers(0, a.H); col = G.integers(0, a.W);
+      if (!a.region_mask || a.region_mask[row * a.W + col] == 1) break;
+      if (tries > (1 << 20)) { if (lane == 0) atomicOr(a.err, 16); break; }
+    }
+    const int bsx = G.integers(a.min_x, a.max_x), bsy = G.integers(a.min_y, a.max_y);
+    // int(ix -/+ bs / 2) of MCMC.py:1758-1761 (truncation towards zero of a half-integer)
+    const int r0 = max(0, (2 * row - bsx) / 2), r1 = min(a.H, (2 * row + bsx) / 2);
+    const int c0 = max(0, (2 * col - bsy) / 2), c1 = min(a.W, (2 * col + bsy) / 2);
+    const int ww = c1 - c0, n = max(0, r1 - r0) * max(0, ww);
+    if (lane == 0) {
+      a.win[4 * rec] = r0; a.win[4 * rec + 1] = r1; a.win[4 * rec + 2] = c0; a.win[4 * rec + 3] = c1;
+      a.blk[4 * rec] = row; a.blk[4 * rec + 1] = col; a.blk[4 * rec + 2] = bsx; a.blk[4 * rec + 3] = bsy;
+      a.cell_off[rec] = (int32_t)(rec * a.max_cells); a.cell_cnt[rec] = (n <= a.max_cells && n <= 1024) ? n : 0;
+    }
+    if ((n > a.max_cells || n > 1024) && lane == 0) atomicOr(a.err, 1);
+    const int nn = (n > a.max_cells || n > 1024) ? 0 : n;
+    for (int p = lane; p < nn; p += 64) order[p] = ((r0 + p / ww) << 16) | (c0 + p % ww);
+    __syncthreads();
+    // rng.shuffle(inds): Fisher-Yates from the back, index by masked rejection on 32-bit words
+    for (int i = nn - 1; i >= 1; --i) {
+      const int jx = (int)G.interval((uint32_t)i);
+      if (lane == 0 && jx != i) { const int32_t t = order[jx]; order[jx] = order[i]; order[i] = t; }
+    }
+    __syncthreads();
+    // cells in visiting order; one standard normal per cell without conditioning data, in that order
+    int count = 0;
+    for (int p0 = 0; p0 < nn; p0 += 64) {
+      const int p = p0 + lane;
+      bool free_cell = false;
+      if (p < nn) {
+        const int i = order[p] >> 16, jj = order[p] & 0xFFFF;
+        a.cells[2 * (rec * a.max_cells + p)] = i; a.cells[2 * (rec * a.max_cells + p) + 1] = jj;
+        free_cell = a.is_data[i * a.W + jj] == 0;
+      }
+      count += __popcll(__ballot(free_cell));
+    }
+    G.normals(count, 0.0, 1.0, zt, lane, A_l, C_l);
+    __syncthreads();
+    int seen = 0;
+    for (int p0 = 0; p0 < nn; p0 += 64) {
+      const int p = p0 + lane;
+      bool free_cell = false;
+      if (p < nn) free_cell = a.is_data[(order[p] >> 16) * a.W + (order[p] & 0xFFFF)] == 0;
+      const unsigned long long m = __ballot(free_cell);
+      const int my = seen + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+      if (p < nn) a.z[rec * a.max_cells + p] = free_cell ? zt[my] : 0.0;
+      seen += __popcll(m);
+    }
+    const double uu = G.next_double();
+    if (lane == 0) a.u[rec] = uu;
+    __syncthreads();
+  }
+  if (lane == 0) { gs[0] = G.s.lo; gs[1] = G.s.hi; gs[4] = G.has32; gs[5] = G.cached; }
+}
+
+hipError_t launch_sgs_draw_pcg64(const SgsDrawArgs& a, uint64_t* states, const uint64_t* jump, const uint64_t* zig, hipStream_t st) {
+  hipLaunchKernelGGL(sgs_draw_pcg64_kernel, dim3(a.n_chains), dim3(64), 0, st, a, states, jump, zig);
+  return hipGetLastError();
+}
+
 // the two constant tables (host side): jump table of the LCG and the ziggurat tables
 void pcg64_host_tables(uint64_t* jump_out, const uint64_t** zig_out) {
   pcg::build_jump_table(jump_out);

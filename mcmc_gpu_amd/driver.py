@@ -349,11 +349,13 @@ def smallScaleChain_mp(n_chains, n_workers, smallScaleChain, initial_beds, ssc_r
     mode 'replay' (default, or smallScaleChain.rng_mode): each chain draws from numpy.random.default_rng(its seed) as the
     reference's workers do -- results and files follow the CPU driver.  mode 'philox': the draws are made on the device (Philox
     counters keyed by the chain's seed, continuing at the iteration count of the seed folder's checkpoint): no host work per
-    iteration."""
+    iteration.  mode 'pcg64': the draws of 'replay' (each chain's numpy.random.default_rng(its seed) stream, bit for bit) made on the
+    device: the reference's chains and files without host work per iteration."""
     from . import sgs
-    philox = (mode or getattr(smallScaleChain, 'rng_mode', 'replay')) == 'philox'
-    if mode not in (None, 'replay', 'philox'):
-        raise ValueError("mode must be 'replay' or 'philox'")
+    mode_eff = mode or getattr(smallScaleChain, 'rng_mode', 'replay')
+    philox = mode_eff == 'philox'
+    if mode not in (None, 'replay', 'philox', 'pcg64'):
+        raise ValueError("mode must be 'replay', 'pcg64' or 'philox'")
     # n_gpus as in largeScaleChain_mp: the chains are independent, so they are sharded contiguously over the ranks (one per
     # GPU, started here when the caller brought no launcher) and the result tuples are gathered at the end
     import os
@@ -389,7 +391,7 @@ def smallScaleChain_mp(n_chains, n_workers, smallScaleChain, initial_beds, ssc_r
             raise ValueError('Philox mode runs the chains of a call in lock-step: their seed folders must hold the same iteration count')
         result, _ = sgs.run_many_sgs(smallScaleChain, beds, rngs, n_iter, only_save_last_bed=True, info_per_iter=10, progress_bar=None,
                                      philox_seeds=[int(v) for v in ssc_rng_seeds[:n_chains]] if philox else None,
-                                     philox_iter0=starts.pop() if philox else 0)
+                                     philox_iter0=starts.pop() if philox else 0, pcg64=(mode_eff == 'pcg64'))
         for i in range(n_chains):
             _msc_save(folders[i], result[i], n_iter, prevs[i])
     else:

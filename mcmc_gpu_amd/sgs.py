@@ -189,9 +189,10 @@ class chain_sgs_gpu:
         """'replay' (default): the draws come from chain.rng in the reference's order (MCMC.py:1750-1797) -- accept masks and
         beds follow the reference on the same seed.  'philox': the draws are made on the device from Philox4x32-10 counters
         keyed by the chain's seed (gsm_sgs_draw_philox) -- no host work per iteration; a chain of its own definition, restated
-        by oracle/sgs_philox_oracle.py."""
-        if mode not in ('replay', 'philox'):
-            raise ValueError("rng mode must be 'replay' or 'philox'")
+        by oracle/sgs_philox_oracle.py.  'pcg64': the draws of 'replay' -- chain.rng's own NumPy PCG64 stream, bit for bit -- made on
+        the device (gsm_sgs_draw_pcg64): the reference's chain on the same seed without host work per iteration."""
+        if mode not in ('replay', 'philox', 'pcg64'):
+            raise ValueError("rng mode must be 'replay', 'pcg64' or 'philox'")
         self.rng_mode = mode
         self.philox_iter = 0
 
@@ -239,10 +240,12 @@ class chain_sgs_gpu:
         loss_mc_cache, loss_data_cache, loss_cache, step_cache, resampled_times, blocks_cache[, sample_values])."""
         if not hasattr(self, 'rng'):
             self.set_random_generator(getattr(self, 'rng_seed', None))
-        philox = getattr(self, 'rng_mode', 'replay') == 'philox'
+        mode = getattr(self, 'rng_mode', 'replay')
+        philox = mode == 'philox'
         out, _ = run_many_sgs(self, [self.initial_bed], [self.rng], n_iter, only_save_last_bed=only_save_last_bed,
                               info_per_iter=info_per_iter, progress_bar=progress_bar,
-                              philox_seeds=[self._philox_seed()] if philox else None, philox_iter0=getattr(self, 'philox_iter', 0))
+                              philox_seeds=[self._philox_seed()] if philox else None, philox_iter0=getattr(self, 'philox_iter', 0),
+                              pcg64=(mode == 'pcg64'))
         if philox:
             self.philox_iter += int(n_iter)
         return out[0]
@@ -253,10 +256,12 @@ def _ptr(t):
 
 
 def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, info_per_iter=100, progress_bar=None, device=None,
-                 philox_seeds=None, philox_iter0=0):
+                 philox_seeds=None, philox_iter0=0, pcg64=False):
     """n small-scale chains of one template (same static fields, variogram, block sizes) in ONE handle.  rngs: one NumPy
     Generator per chain (consumed exactly as chain_sgs.run consumes chain.rng).  philox_seeds (one 64-bit key per chain): Philox
-    mode -- the draws of iterations philox_iter0 .. are made on the device and rngs are not touched.
+    mode -- the draws of iterations philox_iter0 .. are made on the device and rngs are not touched.  pcg64=True: the draws of
+    replay mode (rngs' own PCG64 streams, bit for bit) are made on the device and the generators are left where NumPy would leave
+    them.
     Returns (list of result tuples, rngs)."""
     import torch
     from .engine import GsmEngine
@@ -342,14 +347,21 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
         # the same order whatever is accepted), so a batch of iterations is drawn ahead, uploaded once, and simulated /
         # scored / decided (gsm_sgs_decide) / committed on the device back to back.
         philox = philox_seeds is not None
+        if pcg64 and philox:
+            raise ValueError("choose one of philox_seeds / pcg64")
+        from .engine import GsmEngine
+        if pcg64:
+            d_gen = torch.as_tensor(GsmEngine.pack_pcg64_states(list(rngs)).view(np.int64)).to(dev)
+        philox = philox or pcg64          # both draw on the device: same loop below
         if philox and host_nst is not None:
             raise NotImplementedError("Philox mode of the small-scale chain keeps the whole iteration on the device: the normal-score "
                                       "transformer must be scikit-learn's QuantileTransformer (normal output, one feature) or absent")
         batch = int(os.environ.get('GSM_SGS_BATCH', '32')) if (host_nst is None and not keep_all and not track) else 1
         if philox:
-            if len(philox_seeds) != n:
-                raise ValueError('need one Philox seed per chain')
-            d_seeds = torch.as_tensor(np.asarray([int(x) & 0xFFFFFFFFFFFFFFFF for x in philox_seeds], dtype=np.uint64).view(np.int64)).to(dev)
+            if not pcg64:
+                if len(philox_seeds) != n:
+                    raise ValueError('need one Philox seed per chain')
+                d_seeds = torch.as_tensor(np.asarray([int(x) & 0xFFFFFFFFFFFFFFFF for x in philox_seeds], dtype=np.uint64).view(np.int64)).to(dev)
             d_region = torch.as_tensor(np.ascontiguousarray(chain.region_mask == 1, dtype=np.uint8)).to(dev) if chain.update_in_region else None
             d_isdata = torch.as_tensor(np.ascontiguousarray(cond_is_data, dtype=np.uint8)).to(dev)
         it_done = 0
@@ -364,10 +376,16 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                 d_lprev = f64(loss_prev); d_acc = torch.empty(n, dtype=torch.uint8, device=dev)
             at = lambda t, off_elems: C.c_void_p(t.data_ptr() + int(off_elems) * t.element_size())
             with torch.cuda.device(dev):
-                eng._check(lib.gsm_sgs_draw_philox(h, _ptr(d_seeds), int(philox_iter0) + it_done, kb, _ptr(d_region), _ptr(d_isdata),
-                                                   int(chain.block_min_x), int(chain.block_max_x), int(chain.block_min_y), int(chain.block_max_y),
-                                                   max_cells, _ptr(d_win), _ptr(d_blk), _ptr(d_off), _ptr(d_cnt), _ptr(d_cells), _ptr(d_z),
-                                                   _ptr(d_us), eng._stream()))
+                if pcg64:
+                    eng._check(lib.gsm_sgs_draw_pcg64(h, _ptr(d_gen), kb, _ptr(d_region), _ptr(d_isdata),
+                                                      int(chain.block_min_x), int(chain.block_max_x), int(chain.block_min_y), int(chain.block_max_y),
+                                                      max_cells, _ptr(d_win), _ptr(d_blk), _ptr(d_off), _ptr(d_cnt), _ptr(d_cells), _ptr(d_z),
+                                                      _ptr(d_us), eng._stream()))
+                else:
+                    eng._check(lib.gsm_sgs_draw_philox(h, _ptr(d_seeds), int(philox_iter0) + it_done, kb, _ptr(d_region), _ptr(d_isdata),
+                                                       int(chain.block_min_x), int(chain.block_max_x), int(chain.block_min_y), int(chain.block_max_y),
+                                                       max_cells, _ptr(d_win), _ptr(d_blk), _ptr(d_off), _ptr(d_cnt), _ptr(d_cells), _ptr(d_z),
+                                                       _ptr(d_us), eng._stream()))
                 for j in range(kb):
                     if dev_qt:
                         qt(cur, nxt, 0)
@@ -547,6 +565,9 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
         if host_nst is None:
             bed_c = cur.cpu().numpy()
         res = resampled.cpu().numpy().astype(np.float64)
+        if pcg64:                                  # the generators continue where the device left them, as after NumPy calls
+            for g, st in zip(rngs, GsmEngine.unpack_pcg64_states(d_gen.cpu().numpy().view(np.uint64))):
+                g.bit_generator.state = st
     finally:
         eng.close()
     out = []

@@ -13,6 +13,8 @@ streams, states included):
   Generator.uniform     low + (high - low) * next_double              (distributions.c: random_uniform)
   Generator.integers    int64, [low, high): Lemire's bounded rejection on 32-bit words when the range fits 32 bits
                         (distributions.c: random_bounded_uint64_fill -> buffered_bounded_lemire_uint32)
+  Generator.shuffle     Fisher-Yates from the back with random_interval: masked rejection on 32-bit words (distributions.c:
+                        random_interval; _generator.pyx: shuffle)
   Generator.normal      loc + scale * standard_normal; standard_normal = 256-layer ziggurat (distributions.c:
                         random_standard_normal) with the tables of mcmc_gpu_amd/csrc/ziggurat_tables.h, log1p / exp of libm
 
@@ -101,6 +103,29 @@ class Pcg64:
                 m = self.next_uint32() * rng_excl
                 leftover = m & 0xFFFFFFFF
         return low + (m >> 32)
+
+    def interval(self, mx: int) -> int:
+        """random_interval (distributions.c): uniform on [0, mx] by masked rejection on 32-bit words (mx < 2^32)."""
+        if mx == 0:
+            return 0
+        mask = mx
+        for sh in (1, 2, 4, 8, 16, 32):
+            mask |= mask >> sh
+        assert mx <= 0xFFFFFFFF
+        while True:
+            v = self.next_uint32() & mask
+            if v <= mx:
+                return v
+
+    def shuffle(self, x):
+        """Generator.shuffle(x) along axis 0 (_generator.pyx): for i = n - 1 .. 1: j = random_interval(i); swap rows i and j."""
+        for i in reversed(range(1, len(x))):
+            j = self.interval(i)
+            if i == j:
+                continue
+            tmp = x[j].copy()
+            x[j] = x[i]
+            x[i] = tmp
 
     def standard_normal(self) -> float:
         while True:

@@ -12,6 +12,7 @@ if __name__ == "__main__":
     ap.add_argument('--iters', type=int, default=1000); ap.add_argument('--cpu-iters', type=int, default=0)
     ap.add_argument('--philox', action='store_true', help='Philox mode: the draws are made on the device')
     ap.add_argument('--light', action='store_true'); ap.add_argument('--no-transform', action='store_true')
+    ap.add_argument('--pcg64', action='store_true', help="the chains' own NumPy generator streams advanced on the device (replay mode's chain, no host draws)")
     a = ap.parse_args()
     from mcmc_gpu_amd import sgs, synthetic
     H = a.grid
@@ -20,10 +21,10 @@ if __name__ == "__main__":
     rngs = [np.random.default_rng(900 + i) for i in range(a.chains)]
     sgs.run_many_sgs(ch, beds[:1], [np.random.default_rng(1)], 20)          # warm-up (library load, first launches)
     t0 = time.time()
-    out, _ = sgs.run_many_sgs(ch, beds, rngs, a.iters, philox_seeds=[7000 + i for i in range(a.chains)] if a.philox else None)
+    out, _ = sgs.run_many_sgs(ch, beds, rngs, a.iters, philox_seeds=[7000 + i for i in range(a.chains)] if a.philox else None, pcg64=a.pcg64)
     t_dev = time.time() - t0
     msg = (f"small-scale chain {H}x{H} ({'light' if a.light else 'driver'} config, transform {not a.no_transform}, "
-           f"{'philox' if a.philox else 'replay'}), {a.chains} chains x {a.iters} iterations on the device: {t_dev:.2f} s = "
+           f"{'philox' if a.philox else 'pcg64' if a.pcg64 else 'replay'}), {a.chains} chains x {a.iters} iterations on the device: {t_dev:.2f} s = "
            f"{a.chains * a.iters / t_dev:.0f} chain-iterations/s ({a.iters / t_dev:.0f} it/s per chain, accept {np.mean([o[4].mean() for o in out]):.3f})")
     if a.cpu_iters:
         import sgs_oracle as so

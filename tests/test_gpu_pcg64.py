@@ -126,3 +126,44 @@ def test_pcg64_batches_equal_host_replay_at_headline_geometry():
         np.testing.assert_allclose(x[3], y[3], rtol=1e-10)
         np.testing.assert_allclose(x[0], y[0], rtol=0, atol=1e-9)
     assert 0.3 < np.mean([x[4][1:].mean() for x in a]) < 0.8
+
+
+def test_small_scale_device_draws_equal_numpy():
+    """gsm_sgs_draw_pcg64 against the host mirror's NumPy calls (chain_sgs_gpu._draw_iteration: centre, block sizes, rng.shuffle,
+    one normal per cell without data, rng.random -- MCMC.py:1750-1757, :128, :165, :1797): windows, visiting orders, normals,
+    uniforms and the final generator states, bit for bit, blocks up to 19 x 19."""
+    import ctypes as C
+    from mcmc_gpu_amd import synthetic
+    from mcmc_gpu_amd.engine import GsmEngine, _ptr
+    H, n, kb = 64, 6, 9
+    prob, ch = synthetic.sgs_template(H, transform=False)
+    is_data = ~np.isnan(prob["cond_bed"])
+    gens = [np.random.default_rng(seed=77 + c) for c in range(n)]
+    gens[1].integers(low=0, high=5, size=1)                   # a cached 32-bit half at the start
+    eng = GsmEngine(H, H, n)
+    dev = eng.dev
+    d_gen = torch.as_tensor(GsmEngine.pack_pcg64_states(gens).view(np.int64)).to(dev)
+    max_cells = (ch.block_max_x - 1) * (ch.block_max_y - 1)
+    i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+    d_win, d_blk, d_off, d_cnt = i32(kb, n, 4), i32(kb, n, 4), i32(kb, n), i32(kb, n)
+    d_cells = i32(kb * n * max_cells, 2); d_z = torch.zeros(kb * n * max_cells, dtype=torch.float64, device=dev)
+    d_u = torch.empty((kb, n), dtype=torch.float64, device=dev)
+    d_reg = torch.as_tensor(np.ascontiguousarray(prob["region_mask"] == 1, dtype=np.uint8)).to(dev)
+    d_isd = torch.as_tensor(np.ascontiguousarray(is_data, dtype=np.uint8)).to(dev)
+    eng._check(eng.lib.gsm_sgs_draw_pcg64(eng.h, _ptr(d_gen), kb, _ptr(d_reg), _ptr(d_isd), ch.block_min_x, ch.block_max_x, ch.block_min_y,
+                                          ch.block_max_y, max_cells, _ptr(d_win), _ptr(d_blk), _ptr(d_off), _ptr(d_cnt), _ptr(d_cells), _ptr(d_z),
+                                          _ptr(d_u), eng._stream()))
+    eng._check(eng.lib.gsm_sgs_check(eng.h, eng._stream()))
+    win, blk, cnt = d_win.cpu().numpy(), d_blk.cpu().numpy(), d_cnt.cpu().numpy()
+    cells, z, u = d_cells.cpu().numpy().reshape(kb, n, max_cells, 2), d_z.cpu().numpy().reshape(kb, n, max_cells), d_u.cpu().numpy()
+    states = GsmEngine.unpack_pcg64_states(d_gen.cpu().numpy().view(np.uint64))
+    for c in range(n):
+        for j in range(kb):
+            b, w, inds, zz, uu = ch._draw_iteration(gens[c], is_data)
+            assert tuple(blk[j, c]) == tuple(int(v) for v in b) and tuple(win[j, c]) == tuple(w)
+            assert cnt[j, c] == inds.shape[0]
+            assert np.array_equal(cells[j, c, :cnt[j, c]], inds)
+            assert np.array_equal(z[j, c, :cnt[j, c]], zz)
+            assert u[j, c] == uu
+        assert states[c] == gens[c].bit_generator.state
+    eng.close()

@@ -20,10 +20,13 @@ from test_oracle_sgs_golden import f11_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("tag", ["a", "t", "b", "c"])
-def test_chain_sgs_gpu_equals_reference_at_driver_config(tag):
+@pytest.mark.parametrize("tag,mode", [("a", "replay"), ("t", "replay"), ("b", "replay"), ("c", "replay"), ("a", "pcg64"), ("b", "pcg64")])
+def test_chain_sgs_gpu_equals_reference_at_driver_config(tag, mode):
+    """mode 'replay': the chain's NumPy generator is consumed on the host; 'pcg64': the same stream is advanced on the device
+    (gsm_sgs_draw_pcg64) -- same fixture, same assertions, the final generator state included."""
     g, prob, trend, nst, vp, sp, sigma, stable = f11_case(tag)
     ch = sc.driver_chain(prob, trend, nst, int(g[f"{tag}_seed"]), vp, sp, None, sigma)
+    ch.set_rng_mode(mode)
     n_iter = int(g[f"{tag}_n_iter"])
     out = ch.run(n_iter, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None)
     assert np.array_equal(out[6], g[f"{tag}_blocks"]), "blocks"

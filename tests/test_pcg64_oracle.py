@@ -57,3 +57,18 @@ def test_log1p_restatement_equals_libm_on_the_tail_inputs():
     ref = np.array([math.log1p(-float(v)) for v in u])
     mine = np.array([po.log1p_fdlibm(-float(v)) for v in u])
     assert np.array_equal(ref, mine), int((ref != mine).sum())
+
+
+def test_shuffle_and_offset_integers_equal_numpy():
+    """The small-scale chain's calls (MCMC.py:1750-1757 block sizes with low > 0, :128 rng.shuffle of the block's (row, col) list)."""
+    g, m = _pair(99)
+    for n in (1, 2, 3, 17, 64, 255, 361, 1000):
+        for _ in range(5):
+            a = np.arange(2 * n).reshape(n, 2)
+            b = a.copy()
+            g.shuffle(a)
+            m.shuffle(b)
+            assert np.array_equal(a, b)
+            assert int(g.integers(low=5, high=20, size=1)[0]) == m.integers(5, 20)
+            assert g.random() == m.random()
+            assert g.bit_generator.state == m.numpy_state()
