@@ -343,6 +343,9 @@ def measure_small_scale(H=64, n_chains=4, n_iter=400, cpu_iters=20):
     t0 = time.perf_counter()
     out_p, _ = sgs.run_many_sgs(ch, beds[:n_chains], rngs, n_iter, philox_seeds=[7000 + i for i in range(n_chains)])
     dt_p = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out_g, _ = sgs.run_many_sgs(ch, beds[:n_chains], [np.random.default_rng(900 + i) for i in range(n_chains)], n_iter, pcg64=True)
+    dt_g = time.perf_counter() - t0
     n_big, it_big = 256, 100
     t0 = time.perf_counter()
     out_b, _ = sgs.run_many_sgs(ch, beds[:n_big], [None] * n_big, it_big, philox_seeds=[7000 + i for i in range(n_big)])
@@ -372,6 +375,9 @@ def measure_small_scale(H=64, n_chains=4, n_iter=400, cpu_iters=20):
                                    "(BASELINE configs[0], here on the GPU; replay mode: host draws with the reference's NumPy generator calls)",
                        "iterations": n_iter},
             "accept_rate": float(np.mean([o[4].mean() for o in out])), "timed_seconds": dt,
+            "pcg64_mode": {"value": n_chains * n_iter / dt_g, "unit": "chain-iterations/s", "timed_seconds": dt_g,
+                           "same_chain_as_replay_mode": bool(all(np.array_equal(x[4], y[4]) and np.array_equal(x[6], y[6]) for x, y in zip(out, out_g))),
+                           "note": "the chains' own NumPy PCG64 streams advanced on the device (gsm_sgs_draw_pcg64): replay mode's chain without host draws"},
             "philox_mode": {"value": n_chains * n_iter / dt_p, "unit": "chain-iterations/s", "timed_seconds": dt_p,
                             "accept_rate": float(np.mean([o[4].mean() for o in out_p]))},
             "throughput_256_chains": {

@@ -72,3 +72,26 @@ def test_shuffle_and_offset_integers_equal_numpy():
             assert int(g.integers(low=5, high=20, size=1)[0]) == m.integers(5, 20)
             assert g.random() == m.random()
             assert g.bit_generator.state == m.numpy_state()
+
+
+def test_state_packing_round_trip_and_mode_names():
+    """Host plumbing of the 'pcg64' draw mode: numpy state dict <-> the six 64-bit words handed to gsm_draw_pcg64; mode names."""
+    sys.path.insert(0, str(ROOT))
+    from mcmc_gpu_amd.engine import GsmEngine
+    from mcmc_gpu_amd import MCMC_gpu, sgs, synthetic
+    gens = [np.random.default_rng(seed=s) for s in (1, 2 ** 63 + 5)]
+    gens[1].integers(low=0, high=7, size=1)
+    words = GsmEngine.pack_pcg64_states(gens)
+    assert words.shape == (2, 6) and words.dtype == np.uint64 and words[1, 4] == 1
+    back = GsmEngine.unpack_pcg64_states(words)
+    assert back == [g.bit_generator.state for g in gens]
+    m = po.Pcg64(int(words[1, 0]) | (int(words[1, 1]) << 64), int(words[1, 2]) | (int(words[1, 3]) << 64), int(words[1, 4]), int(words[1, 5]))
+    assert m.integers(0, 100) == int(gens[1].integers(low=0, high=100, size=1)[0])
+    with pytest.raises(ValueError):
+        GsmEngine.pack_pcg64_states([np.random.Generator(np.random.MT19937(3))])
+    prob, ch, rf = synthetic.template(64)
+    ch.set_rng_mode('pcg64'); assert ch.rng_mode == 'pcg64'
+    with pytest.raises(ValueError):
+        ch.set_rng_mode('numpy')
+    _, s_ch = synthetic.sgs_template(32, transform=False)
+    s_ch.set_rng_mode('pcg64'); assert s_ch.rng_mode == 'pcg64'
