@@ -468,7 +468,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
-    inner = args.inner if args.generator == "spectral" else min(args.inner, 128)
+    inner = args.inner if args.generator == "spectral" else min(args.inner, 256)
     out = measure(args, args.grid, args.chains, args.generator, args.state, inner, args.batch, args.steps, args.warmup,
                   rank, world, dev, classes=args.classes)
     if rank == 0:
@@ -480,7 +480,7 @@ def main():
             out["cpu_baseline"] = cpu_res
     if world == 1 and default_workload and not args.no_extras:
         extras = {}
-        for name, kw in (("configs[3]", dict(H=512, n_local=1024, generator="cholesky", state="f64", inner=128, batch=64, steps=3, warmup=1)),
+        for name, kw in (("configs[3]", dict(H=512, n_local=1024, generator="cholesky", state="f64", inner=256, batch=128, steps=3, warmup=1)),
                          ("configs[4] one GPU's shard", dict(H=1024, n_local=512, generator="spectral", state="f32", inner=512, batch=32, steps=3, warmup=1))):
             t0 = time.perf_counter()
             try:

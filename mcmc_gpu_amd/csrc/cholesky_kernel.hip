@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void cz_gemm_dma_kernel(const ProposeArgs a, c
     if (k0 + 16 < kend) request(buf ^ 1);                     // its last readers passed the barrier that ended the previous iteration
     const double* As = &stage[buf][0];
     const double* Bs = As + kStageA;
+    if (k0 < n0 + wn + 64)                                     // beyond this wave's own diagonal U[k][n] = 0: no MFMAs (wave-uniform)
 #pragma unroll
     for (int kk = 0; kk < 16; kk += 4) {
       const double a0 = As[(kk + l4) * kTS + wp + l15], a1 = As[(kk + l4) * kTS + wp + 16 + l15];
