@@ -369,6 +369,34 @@ int gsm_sgs_commit_map(gsm_handle h, double* cur, const double* proposed, uint32
 int gsm_sgs_commit(gsm_handle h, double* cur, double* next, uint32_t* resampled, const int32_t* windows,
                    const uint8_t* accept, void* stream);
 
+/* One batch of small-scale iterations in ONE call: for j < n_iters, in the order of chain_sgs.run's loop body
+ * (MCMC.py:1741-1822) -- [gsm_qt_transform cur -> next] gsm_sgs_blocks_batch [gsm_sgs_finish | gsm_qt_transform next ->
+ * proposed, gsm_sgs_loss, gsm_sgs_decide, gsm_sgs_commit(_map)] -- with iteration j's draws at windows + 4*n_chains*j,
+ * cell_off + cell_off_stride*j, cell_cnt + n_chains*j (or NULL), u + n_chains*j and records at loss_rec + j / acc_rec + j
+ * (rec_stride = n_iters).  cell_base (HOST, n_iters entries, or NULL = 0): iteration j's cells / z start at
+ * cells + 2*cell_base[j] / z + cell_base[j] (the tightly packed lists of replay mode).
+ * use_graph != 0 (and cell_base == NULL, stream != NULL): the launch sequence is captured into a hipGraph the second time the
+ * SAME batch (every byte of the struct -- zero it before filling -- and n_iters) is submitted and replayed afterwards: one
+ * launch per batch instead of up to 7 per iteration; the device buffers must then be static and refilled in place
+ * (gsm_sgs_draw_philox / gsm_sgs_draw_pcg64 do).  Asynchronous; gsm_sgs_check reports a raised device flag.
+ * gsm_sgs_graph_replays: how many batches of this handle were graph launches (diagnostics / tests). */
+typedef struct gsm_sgs_batch {
+  double* cur; double* next; double* proposed;            /* proposed: only with a transformer */
+  const double* zcond; const double* trend;               /* trend NULL: not detrended */
+  const double* qt_quantiles; const double* qt_references;
+  double* energy; double* state;                          /* windowed finish only */
+  const double* x_axis; const double* y_axis; const double* lag_cov;
+  const int32_t* windows; const int32_t* cell_off; const int32_t* cell_cnt; const int32_t* cells; const double* z;
+  const int64_t* cell_base;                               /* HOST or NULL */
+  const double* u;
+  uint32_t* resampled; double* loss; int32_t* bad; double* loss_prev; uint8_t* accept; double* loss_rec; uint8_t* acc_rec;
+  double radius, sill;
+  int64_t cell_off_stride;
+  int32_t qt_n, windowed, lag_mi, lag_mj, hw, num_points, max_cells, use_graph;
+} gsm_sgs_batch;
+int gsm_sgs_iterate(gsm_handle h, const gsm_sgs_batch* batch, int32_t n_iters, void* stream);
+int gsm_sgs_graph_replays(gsm_handle h);
+
 /* Setup-time distance transform: dist[i] = Euclidean distance from cell i (coordinates xx[i], yy[i]) to the nearest
  * cell with mask[i] != 0, all [dev, H*W].  Exact (brute force over the masked cells, same dx*dx + dy*dy, sqrt
  * arithmetic as the KD-tree query).  Synchronises the stream.

@@ -135,6 +135,15 @@ class RfParams(C.Structure):
                 ("model", C.c_int32), ("isotropic", C.c_int32), ("generator", C.c_int32), ("reserved", C.c_int32)]
 
 
+class SgsBatch(C.Structure):
+    """Mirror of gsm_sgs_batch (include/gsm.h)."""
+    _fields_ = ([(k, C.c_void_p) for k in ("cur", "next", "proposed", "zcond", "trend", "qt_quantiles", "qt_references", "energy", "state",
+                                          "x_axis", "y_axis", "lag_cov", "windows", "cell_off", "cell_cnt", "cells", "z", "cell_base", "u",
+                                          "resampled", "loss", "bad", "loss_prev", "accept", "loss_rec", "acc_rec")] +
+                [("radius", C.c_double), ("sill", C.c_double), ("cell_off_stride", C.c_int64)] +
+                [(k, C.c_int32) for k in ("qt_n", "windowed", "lag_mi", "lag_mj", "hw", "num_points", "max_cells", "use_graph")])
+
+
 class Vario(C.Structure):
     """Mirror of gsm_vario (include/gsm.h)."""
     _fields_ = [("azimuth", C.c_double), ("major_range", C.c_double), ("minor_range", C.c_double),
@@ -199,6 +208,8 @@ def load() -> C.CDLL:
     lib.gsm_sgs_commit.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.gsm_sgs_blocks_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, dbl, i32, dbl, vp, vp, vp, vp, i32, vp]
     lib.gsm_sgs_check.argtypes = [vp, vp]
+    lib.gsm_sgs_iterate.argtypes = [vp, C.POINTER(SgsBatch), i32, vp]
+    lib.gsm_sgs_graph_replays.argtypes = [vp]
     lib.gsm_draw_pcg64.argtypes = [vp, i32, C.POINTER(RfParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.gsm_sgs_state_init.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.gsm_sgs_finish.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]

@@ -33,6 +33,8 @@ struct gsm_context {
   double* d_sgs_part_sum = nullptr; int32_t* d_sgs_part_bad = nullptr; size_t sgs_part_cap = 0;   // gsm_sgs_loss partial sums
   // gsm_sgs_blocks scratch: visiting ranks + one record per (chain, cell slot), see SgsArgs
   void* d_sgs_rec = nullptr; size_t sgs_rec_cells = 0;
+  // gsm_sgs_iterate: the captured launch sequence of one batch (hipGraph), keyed by the bytes of its gsm_sgs_batch + n_iters
+  std::vector<char> sgs_graph_key; hipGraphExec_t sgs_graph_exec = nullptr; int sgs_graph_replays = 0;
   uint64_t* d_pcg_tab = nullptr;   // gsm_draw_pcg64: LCG jump table (512 words) + ziggurat tables (768 words)
   int32_t* d_k2_off = nullptr;
   double k2_resolution = 0.0;
@@ -137,6 +139,7 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_mathtab) hipFree(h->d_mathtab);
   if (h->d_sgs_part_sum) { hipFree(h->d_sgs_part_sum); hipFree(h->d_sgs_part_bad); }
   if (h->d_sgs_rec) hipFree(h->d_sgs_rec);
+  if (h->sgs_graph_exec) hipGraphExecDestroy(h->sgs_graph_exec);
   if (h->d_pcg_tab) hipFree(h->d_pcg_tab);
   if (h->d_k2_off) hipFree(h->d_k2_off);
   if (h->d_factors) hipFree(h->d_factors);
@@ -1029,6 +1032,82 @@ extern "C" int gsm_sgs_commit(gsm_handle h, double* cur, double* next, uint32_t*
   HIPCHK(h, launch_sgs_commit(h->H, h->W, h->n_chains, cur, next, resampled, windows, accept, (hipStream_t)stream));
   return GSM_OK;
 }
+
+// ---- one batch of small-scale iterations in ONE call (and, when the buffers are static, one hipGraph launch) ----------------
+static int sgs_issue(gsm_handle h, const gsm_sgs_batch* b, int32_t n_iters, void* st) {
+  const int64_t n = h->n_chains;
+  const bool qt = b->qt_n > 0;
+  const int64_t map = n * (int64_t)h->H * h->W;
+  for (int32_t j = 0; j < n_iters; ++j) {
+    const int32_t* win = b->windows + 4 * n * j;
+    const double* u = b->u + n * j;
+    const int64_t base = b->cell_base ? b->cell_base[j] : 0;
+    int rc;
+    if (qt && (rc = gsm_qt_transform(h, b->qt_quantiles, b->qt_references, b->qt_n, b->cur, b->next, map, 0, st))) return rc;   // MCMC.py:1766
+    if ((rc = gsm_sgs_blocks_batch(h, b->next, b->zcond, win, b->x_axis, b->y_axis, b->lag_cov, b->lag_mi, b->lag_mj, b->hw, b->radius,
+                                   b->num_points, b->sill, b->cell_off + b->cell_off_stride * j, b->cell_cnt ? b->cell_cnt + n * j : nullptr,
+                                   b->cells + 2 * base, b->z + base, b->max_cells, st))) return rc;
+    if (b->windowed) {
+      if ((rc = gsm_sgs_finish(h, b->cur, b->next, b->trend, b->energy, b->state, win, u, b->resampled, b->accept,
+                               b->loss_rec ? b->loss_rec + j : nullptr, b->acc_rec ? b->acc_rec + j : nullptr, n_iters, st))) return rc;
+      continue;
+    }
+    if (qt && (rc = gsm_qt_transform(h, b->qt_quantiles, b->qt_references, b->qt_n, b->next, b->proposed, map, 1, st))) return rc;  // MCMC.py:1777
+    if ((rc = gsm_sgs_loss(h, qt ? b->proposed : b->next, b->trend, b->loss, b->bad, st))) return rc;
+    if ((rc = gsm_sgs_decide(h, b->loss, b->bad, u, b->loss_prev, b->accept, b->loss_rec ? b->loss_rec + j : nullptr,
+                             b->acc_rec ? b->acc_rec + j : nullptr, n_iters, st))) return rc;
+    rc = qt ? gsm_sgs_commit_map(h, b->cur, b->proposed, b->resampled, win, b->accept, st)
+            : gsm_sgs_commit(h, b->cur, b->next, b->resampled, win, b->accept, st);
+    if (rc) return rc;
+  }
+  return GSM_OK;
+}
+
+extern "C" int gsm_sgs_iterate(gsm_handle h, const gsm_sgs_batch* b, int32_t n_iters, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!b || n_iters < 1) return fail(h, GSM_E_ARG, "gsm_sgs_iterate: NULL batch / n_iters < 1");
+  if (!b->cur || !b->next || !b->windows || !b->cell_off || !b->cells || !b->z || !b->u || !b->resampled || !b->accept)
+    return fail(h, GSM_E_ARG, "gsm_sgs_iterate: NULL pointer");
+  if (b->qt_n < 0 || (b->qt_n > 0 && (!b->qt_quantiles || !b->qt_references || !b->proposed)))
+    return fail(h, GSM_E_ARG, "gsm_sgs_iterate: a transformer needs qt_quantiles, qt_references and the `proposed` planes");
+  if (b->windowed && (b->qt_n > 0 || !b->energy || !b->state))
+    return fail(h, GSM_E_ARG, "gsm_sgs_iterate: the windowed finish needs energy / state and no transformer");
+  if (!b->windowed && (!b->loss || !b->bad || !b->loss_prev)) return fail(h, GSM_E_ARG, "gsm_sgs_iterate: loss / bad / loss_prev are NULL");
+  if (b->cell_off_stride < h->n_chains) return fail(h, GSM_E_ARG, "gsm_sgs_iterate: cell_off_stride must be >= n_chains");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  // Graph replay needs every pointer of the batch to be the same as at capture, a capturable (non-NULL) stream, and all lazy
+  // allocations of the launch path made: the first call with a given batch runs eagerly, the second captures, later ones replay.
+  const bool graphable = b->use_graph && st != nullptr && !b->cell_base;
+  if (!graphable) return sgs_issue(h, b, n_iters, stream);
+  std::vector<char> key(sizeof(gsm_sgs_batch) + sizeof(int32_t));
+  memcpy(key.data(), b, sizeof(gsm_sgs_batch));
+  memcpy(key.data() + sizeof(gsm_sgs_batch), &n_iters, sizeof(int32_t));
+  if (key != h->sgs_graph_key) {
+    if (h->sgs_graph_exec) { hipGraphExecDestroy(h->sgs_graph_exec); h->sgs_graph_exec = nullptr; }
+    h->sgs_graph_key = key;
+    return sgs_issue(h, b, n_iters, stream);
+  }
+  if (!h->sgs_graph_exec) {
+    HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = sgs_issue(h, b, n_iters, stream);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc || e != hipSuccess) {
+      if (g) hipGraphDestroy(g);
+      h->sgs_graph_key.clear();
+      return rc ? rc : fail(h, GSM_E_HIP, std::string("gsm_sgs_iterate: hipStreamEndCapture: ") + hipGetErrorString(e));
+    }
+    e = hipGraphInstantiate(&h->sgs_graph_exec, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) { h->sgs_graph_exec = nullptr; h->sgs_graph_key.clear(); return fail(h, GSM_E_HIP, std::string("gsm_sgs_iterate: hipGraphInstantiate: ") + hipGetErrorString(e)); }
+  }
+  HIPCHK(h, hipGraphLaunch(h->sgs_graph_exec, st));
+  ++h->sgs_graph_replays;
+  return GSM_OK;
+}
+
+extern "C" int gsm_sgs_graph_replays(gsm_handle h) { return h ? h->sgs_graph_replays : GSM_E_ARG; }
 
 extern "C" int gsm_min_dist_from_mask(gsm_handle h, const double* xx, const double* yy, const uint8_t* mask,
                                       double* dist, void* stream) {

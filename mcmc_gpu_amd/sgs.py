@@ -251,6 +251,9 @@ class chain_sgs_gpu:
         return out[0]
 
 
+LAST_GRAPH_REPLAYS = 0      # batches of the last device-draw run_many_sgs call that were hipGraph launches (gsm_sgs_iterate)
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -364,18 +367,50 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                 d_seeds = torch.as_tensor(np.asarray([int(x) & 0xFFFFFFFFFFFFFFFF for x in philox_seeds], dtype=np.uint64).view(np.int64)).to(dev)
             d_region = torch.as_tensor(np.ascontiguousarray(chain.region_mask == 1, dtype=np.uint8)).to(dev) if chain.update_in_region else None
             d_isdata = torch.as_tensor(np.ascontiguousarray(cond_is_data, dtype=np.uint8)).to(dev)
+        from ._lib import SgsBatch
+
+        def make_batch(d_win, d_off, off_stride, d_cnt, d_cells, d_z, d_us, d_lrec, d_arec, cell_base=None, use_graph=False):
+            """gsm_sgs_batch (include/gsm.h) of one batch of iterations: the loop body of chain_sgs.run (MCMC.py:1741-1822) is issued
+            by ONE gsm_sgs_iterate call -- and, with static buffers, replayed as one hipGraph launch."""
+            b = SgsBatch()
+            pv = lambda t: t.data_ptr() if t is not None else None
+            b.cur, b.next, b.proposed = pv(cur), pv(nxt), pv(prop) if dev_qt else None
+            b.zcond, b.trend = pv(d_zcond), pv(d_trend)
+            if dev_qt:
+                b.qt_quantiles, b.qt_references, b.qt_n = pv(d_q), pv(d_ref), nq
+            if windowed:
+                b.energy, b.state, b.windowed = pv(d_energy), pv(d_state), 1
+            b.x_axis, b.y_axis, b.lag_cov = pv(d_xs), pv(d_ys), pv(d_lag)
+            b.windows, b.cell_off, b.cell_cnt, b.cells, b.z, b.u = pv(d_win), pv(d_off), pv(d_cnt), pv(d_cells), pv(d_z), pv(d_us)
+            b.cell_off_stride = off_stride
+            if cell_base is not None:
+                b.cell_base = cell_base.ctypes.data
+            b.resampled, b.loss, b.bad, b.loss_prev, b.accept = pv(resampled), pv(d_loss), pv(d_bad), pv(d_lprev), pv(d_acc)
+            b.loss_rec, b.acc_rec = pv(d_lrec), pv(d_arec)
+            b.radius, b.sill = rad, float(vario["sill"])
+            b.lag_mi, b.lag_mj, b.hw, b.num_points, b.max_cells, b.use_graph = lag_mi, lag_mj, hw, npts, max_cells, int(use_graph)
+            return b
+
         it_done = 0
+        if philox and n_iter > 0:
+            # device draws refill the SAME buffers batch after batch: the launch sequence of a full batch is a hipGraph
+            # (captured on a side stream -- the legacy default stream cannot be captured)
+            use_graph = batch > 1 and os.environ.get('GSM_SGS_GRAPH', '1') != '0'
+            i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+            kmax = min(batch, n_iter)
+            b_win, b_blk, b_off, b_cnt = i32(kmax * n * 4), i32(kmax * n * 4), i32(kmax * n), i32(kmax * n)
+            d_cells = i32(kmax * n * max_cells, 2); d_z = torch.empty(kmax * n * max_cells, dtype=torch.float64, device=dev)
+            b_us = torch.empty(kmax * n, dtype=torch.float64, device=dev)
+            b_lrec = torch.empty(n * kmax, dtype=torch.float64, device=dev); b_arec = torch.empty(n * kmax, dtype=torch.uint8, device=dev)
+            d_lprev = f64(loss_prev); d_acc = torch.empty(n, dtype=torch.uint8, device=dev)
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
         while philox and it_done < n_iter:
             kb = min(batch, n_iter - it_done)
-            i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
-            d_win, d_blk, d_off, d_cnt = i32(kb, n, 4), i32(kb, n, 4), i32(kb, n), i32(kb, n)
-            d_cells = i32(kb * n * max_cells, 2); d_z = torch.empty(kb * n * max_cells, dtype=torch.float64, device=dev)
-            d_us = torch.empty((kb, n), dtype=torch.float64, device=dev)
-            d_lrec = torch.empty((n, kb), dtype=torch.float64, device=dev); d_arec = torch.empty((n, kb), dtype=torch.uint8, device=dev)
-            if it_done == 0:
-                d_lprev = f64(loss_prev); d_acc = torch.empty(n, dtype=torch.uint8, device=dev)
-            at = lambda t, off_elems: C.c_void_p(t.data_ptr() + int(off_elems) * t.element_size())
-            with torch.cuda.device(dev):
+            d_win, d_blk, d_off, d_cnt = b_win[:kb * n * 4].view(kb, n, 4), b_blk[:kb * n * 4].view(kb, n, 4), b_off[:kb * n].view(kb, n), b_cnt[:kb * n].view(kb, n)
+            d_us = b_us[:kb * n].view(kb, n)
+            d_lrec, d_arec = b_lrec[:n * kb].view(n, kb), b_arec[:n * kb].view(n, kb)
+            with torch.cuda.device(dev), torch.cuda.stream(side):
                 if pcg64:
                     eng._check(lib.gsm_sgs_draw_pcg64(h, _ptr(d_gen), kb, _ptr(d_region), _ptr(d_isdata),
                                                       int(chain.block_min_x), int(chain.block_max_x), int(chain.block_min_y), int(chain.block_max_y),
@@ -386,29 +421,13 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                                                        int(chain.block_min_x), int(chain.block_max_x), int(chain.block_min_y), int(chain.block_max_y),
                                                        max_cells, _ptr(d_win), _ptr(d_blk), _ptr(d_off), _ptr(d_cnt), _ptr(d_cells), _ptr(d_z),
                                                        _ptr(d_us), eng._stream()))
-                for j in range(kb):
-                    if dev_qt:
-                        qt(cur, nxt, 0)
-                    eng._check(lib.gsm_sgs_blocks_batch(h, _ptr(nxt), _ptr(d_zcond), at(d_win, 4 * n * j), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), lag_mi, lag_mj, hw,
-                                                        rad, npts, float(vario["sill"]), at(d_off, n * j), at(d_cnt, n * j), _ptr(d_cells), _ptr(d_z),
-                                                        max_cells, eng._stream()))
-                    if windowed:
-                        eng._check(lib.gsm_sgs_finish(h, _ptr(cur), _ptr(nxt), _ptr(d_trend), _ptr(d_energy), _ptr(d_state), at(d_win, 4 * n * j),
-                                                      at(d_us, n * j), _ptr(resampled), _ptr(d_acc), at(d_lrec, j), at(d_arec, j), kb, eng._stream()))
-                        continue
-                    if dev_qt:
-                        qt(nxt, prop, 1)
-                    eng._check(lib.gsm_sgs_loss(h, _ptr(prop if dev_qt else nxt), _ptr(d_trend), _ptr(d_loss), _ptr(d_bad), eng._stream()))
-                    eng._check(lib.gsm_sgs_decide(h, _ptr(d_loss), _ptr(d_bad), at(d_us, n * j), _ptr(d_lprev), _ptr(d_acc),
-                                                  at(d_lrec, j), at(d_arec, j), kb, eng._stream()))
-                    if dev_qt:
-                        eng._check(lib.gsm_sgs_commit_map(h, _ptr(cur), _ptr(prop), _ptr(resampled), at(d_win, 4 * n * j), _ptr(d_acc), eng._stream()))
-                    else:
-                        eng._check(lib.gsm_sgs_commit(h, _ptr(cur), _ptr(nxt), _ptr(resampled), at(d_win, 4 * n * j), _ptr(d_acc), eng._stream()))
+                bt = make_batch(d_win, d_off, n, d_cnt, d_cells, d_z, d_us, d_lrec, d_arec, use_graph=use_graph)
+                eng._check(lib.gsm_sgs_iterate(h, C.byref(bt), kb, eng._stream()))
                 eng._check(lib.gsm_sgs_check(h, eng._stream()))
-            loss_cache[:, it_done:it_done + kb] = d_lrec.cpu().numpy()
-            step_cache[:, it_done:it_done + kb] = d_arec.cpu().numpy()
-            blocks_cache[:, it_done:it_done + kb] = d_blk.cpu().numpy().transpose(1, 0, 2)
+                lrec_h, arec_h, blk_h = d_lrec.cpu().numpy(), d_arec.cpu().numpy(), d_blk.cpu().numpy()
+            loss_cache[:, it_done:it_done + kb] = lrec_h
+            step_cache[:, it_done:it_done + kb] = arec_h
+            blocks_cache[:, it_done:it_done + kb] = blk_h.transpose(1, 0, 2)
             if keep_all or track:                      # per-iteration bed records (chain_sgs.run, MCMC.py:1814-1822): kb == 1 here
                 bed_c = cur.cpu().numpy()
                 if keep_all:
@@ -417,6 +436,10 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                     for c in range(n):
                         sample_values[c, :, it_done] = bed_c[c][ij[:, 0], ij[:, 1]]
             it_done += kb
+            if it_done >= n_iter:
+                torch.cuda.current_stream(dev).wait_stream(side)
+                global LAST_GRAPH_REPLAYS
+                LAST_GRAPH_REPLAYS = int(lib.gsm_sgs_graph_replays(h))
             if progress_bar is not None:
                 el = time.time() - t0
                 print(f"Chain {getattr(chain, 'chain_id', 0)} ({str(getattr(chain, 'seed', 'Unknown'))[:6]}): "
@@ -449,27 +472,9 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
             d_win = torch.as_tensor(d['wins']).to(dev); d_off = torch.as_tensor(d['offs']).to(dev); d_us = torch.as_tensor(d['us']).to(dev)
             d_cells = torch.as_tensor(d['cells']).to(dev); d_z = torch.as_tensor(d['z']).to(dev)
             d_lrec = torch.empty((n, kb), dtype=torch.float64, device=dev); d_arec = torch.empty((n, kb), dtype=torch.uint8, device=dev)
-            at = lambda t, off_elems: C.c_void_p(t.data_ptr() + int(off_elems) * t.element_size())
             with torch.cuda.device(dev):
-                for j in range(kb):
-                    if dev_qt:
-                        qt(cur, nxt, 0)                       # the whole map to normal scores (MCMC.py:1766)
-                    eng._check(lib.gsm_sgs_blocks_batch(h, _ptr(nxt), _ptr(d_zcond), at(d_win, 4 * n * j), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), lag_mi, lag_mj, hw,
-                                                        rad, npts, float(vario["sill"]), at(d_off, (n + 1) * j), None, at(d_cells, 2 * bases[j]),
-                                                        at(d_z, bases[j]), max_cells, eng._stream()))
-                    if windowed:
-                        eng._check(lib.gsm_sgs_finish(h, _ptr(cur), _ptr(nxt), _ptr(d_trend), _ptr(d_energy), _ptr(d_state), at(d_win, 4 * n * j),
-                                                      at(d_us, n * j), _ptr(resampled), _ptr(d_acc), at(d_lrec, j), at(d_arec, j), kb, eng._stream()))
-                        continue
-                    if dev_qt:
-                        qt(nxt, prop, 1)                      # ... and back (MCMC.py:1777)
-                    eng._check(lib.gsm_sgs_loss(h, _ptr(prop if dev_qt else nxt), _ptr(d_trend), _ptr(d_loss), _ptr(d_bad), eng._stream()))
-                    eng._check(lib.gsm_sgs_decide(h, _ptr(d_loss), _ptr(d_bad), at(d_us, n * j), _ptr(d_lprev), _ptr(d_acc),
-                                                  at(d_lrec, j), at(d_arec, j), kb, eng._stream()))
-                    if dev_qt:
-                        eng._check(lib.gsm_sgs_commit_map(h, _ptr(cur), _ptr(prop), _ptr(resampled), at(d_win, 4 * n * j), _ptr(d_acc), eng._stream()))
-                    else:
-                        eng._check(lib.gsm_sgs_commit(h, _ptr(cur), _ptr(nxt), _ptr(resampled), at(d_win, 4 * n * j), _ptr(d_acc), eng._stream()))
+                bt = make_batch(d_win, d_off, n + 1, None, d_cells, d_z, d_us, d_lrec, d_arec, cell_base=np.ascontiguousarray(bases, dtype=np.int64))
+                eng._check(lib.gsm_sgs_iterate(h, C.byref(bt), kb, eng._stream()))
             d['keep'] = (d_win, d_off, d_us, d_cells, d_z)      # alive until the batch is finished
             d['lrec'], d['arec'] = d_lrec, d_arec
 

@@ -384,3 +384,26 @@ def test_philox_mode_keeps_per_iteration_records():
     np.testing.assert_allclose(full[7][1, 1:], full[0][1:, 20, 11] - tr[20, 11], rtol=0, atol=1e-9)
     moved = np.abs(np.diff(full[0], axis=0)).max(axis=(1, 2)) > 0          # the bed changes exactly on accepted iterations
     assert np.array_equal(moved, full[4][1:].astype(bool))
+
+
+@pytest.mark.parametrize("transform,pcg64", [(True, False), (False, False), (True, True)])
+def test_graph_replay_of_a_batch_equals_the_eager_launches(monkeypatch, transform, pcg64):
+    """gsm_sgs_iterate issues the loop body of chain_sgs.run (MCMC.py:1741-1822) for a batch of iterations; with device draws the
+    buffers are static, so the second full batch is captured into a hipGraph and later ones are replays.  GSM_SGS_GRAPH=0 issues
+    the same launches one by one: every record must be identical bit for bit."""
+    from mcmc_gpu_amd import sgs, synthetic
+    res, replays = [], []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GSM_SGS_GRAPH", flag)
+        prob, ch = synthetic.sgs_template(32, transform=transform, light=True)
+        beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(5)]
+        rngs = [np.random.default_rng(70 + i) for i in range(5)]
+        out, rngs = sgs.run_many_sgs(ch, beds, rngs, 200, philox_seeds=None if pcg64 else [11 + i for i in range(5)], pcg64=pcg64)
+        res.append((out, [r.bit_generator.state for r in rngs]))
+        replays.append(sgs.LAST_GRAPH_REPLAYS)
+    assert replays[0] >= 4 and replays[1] == 0, replays          # 200 iterations = 6 full batches of 32 (eager, capture + 5 launches) + 8
+    (a, sa), (b, sb) = res
+    assert sa == sb
+    for x, y in zip(a, b):
+        for k in (0, 3, 4, 5, 6):
+            assert np.array_equal(np.asarray(x[k], dtype=float), np.asarray(y[k], dtype=float), equal_nan=True), k
