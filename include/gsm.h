@@ -369,6 +369,16 @@ int gsm_sgs_commit_map(gsm_handle h, double* cur, const double* proposed, uint32
 int gsm_sgs_commit(gsm_handle h, double* cur, double* next, uint32_t* resampled, const int32_t* windows,
                    const uint8_t* accept, void* stream);
 
+/* Kriging type of the gsm_sgs_blocks* calls that follow on this handle.  GSM_KRIGING_ORDINARY (the default; what
+ * chain_sgs.run uses, MCMC.py:1774 passes no ktype): ok_solve, the (n+1) x (n+1) system with the Lagrange row, estimate around
+ * the LOCAL mean of the neighbours (_krige.py:5-44).  GSM_KRIGING_SIMPLE: sk_solve, Sigma w = rho, estimate
+ * global_mean + sum w (v - global_mean) (_krige.py:46-81); global_mean [dev, n_chains] = the mean of each chain's conditioning
+ * values BEFORE the call (MCMC.py:81, np.mean(out_grid[cond_msk])), read when the blocks are simulated.
+ * Replaces: the ktype argument of MCMC.sgs (MCMC.py:91, :158-161). */
+#define GSM_KRIGING_ORDINARY 0
+#define GSM_KRIGING_SIMPLE 1
+int gsm_sgs_set_kriging(gsm_handle h, int32_t ktype, const double* global_mean);
+
 /* One batch of small-scale iterations in ONE call: for j < n_iters, in the order of chain_sgs.run's loop body
  * (MCMC.py:1741-1822) -- [gsm_qt_transform cur -> next] gsm_sgs_blocks_batch [gsm_sgs_finish | gsm_qt_transform next ->
  * proposed, gsm_sgs_loss, gsm_sgs_decide, gsm_sgs_commit(_map)] -- with iteration j's draws at windows + 4*n_chains*j,

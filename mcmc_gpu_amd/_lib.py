@@ -210,6 +210,7 @@ def load() -> C.CDLL:
     lib.gsm_sgs_check.argtypes = [vp, vp]
     lib.gsm_sgs_iterate.argtypes = [vp, C.POINTER(SgsBatch), i32, vp]
     lib.gsm_sgs_graph_replays.argtypes = [vp]
+    lib.gsm_sgs_set_kriging.argtypes = [vp, i32, vp]
     lib.gsm_draw_pcg64.argtypes = [vp, i32, C.POINTER(RfParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.gsm_sgs_state_init.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.gsm_sgs_finish.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]

@@ -34,6 +34,7 @@ struct gsm_context {
   // gsm_sgs_blocks scratch: visiting ranks + one record per (chain, cell slot), see SgsArgs
   void* d_sgs_rec = nullptr; size_t sgs_rec_cells = 0;
   // gsm_sgs_iterate: the captured launch sequence of one batch (hipGraph), keyed by the bytes of its gsm_sgs_batch + n_iters
+  int sgs_ktype = 0; const double* sgs_gmean = nullptr;        // gsm_sgs_set_kriging
   std::vector<char> sgs_graph_key; hipGraphExec_t sgs_graph_exec = nullptr; int sgs_graph_replays = 0;
   uint64_t* d_pcg_tab = nullptr;   // gsm_draw_pcg64: LCG jump table (512 words) + ziggurat tables (768 words)
   int32_t* d_k2_off = nullptr;
@@ -846,6 +847,7 @@ static int sgs_fill(gsm_handle h, SgsArgs& a, double* grids, const double* zcond
   a.grid = grids; a.zcond = zcond; a.win = windows; a.xs = x_axis; a.ys = y_axis; a.lag = lag_cov;
   a.hw = hw; a.mi = lag_mi; a.mj = lag_mj; a.num_points = num_points; a.radius = radius; a.sill = sill;
   a.cell_off = cell_off; a.cells = cells; a.z = z; a.err = h->d_err; a.max_cells = max_cells;
+  a.ktype = h->sgs_ktype; a.gmean = h->sgs_gmean;
   return GSM_OK;
 }
 
@@ -895,6 +897,16 @@ extern "C" int gsm_sgs_blocks_batch(gsm_handle h, double* grids, const double* z
   if (rc) return rc;
   a.cell_cnt = cell_cnt; a.trace = nullptr; a.nbr_trace = nullptr;
   HIPCHK(h, launch_sgs_blocks(a, a.max_cells, (hipStream_t)stream));
+  return GSM_OK;
+}
+
+extern "C" int gsm_sgs_set_kriging(gsm_handle h, int32_t ktype, const double* global_mean) {
+  if (!h) return GSM_E_ARG;
+  if (ktype != GSM_KRIGING_ORDINARY && ktype != GSM_KRIGING_SIMPLE) return fail(h, GSM_E_ARG, "gsm_sgs_set_kriging: ktype must be GSM_KRIGING_ORDINARY or GSM_KRIGING_SIMPLE");
+  if (ktype == GSM_KRIGING_SIMPLE && !global_mean) return fail(h, GSM_E_ARG, "gsm_sgs_set_kriging: simple kriging needs the global mean of every chain");
+  h->sgs_ktype = ktype; h->sgs_gmean = ktype == GSM_KRIGING_SIMPLE ? global_mean : nullptr;
+  h->sgs_graph_key.clear();                     // a captured batch baked the old choice into its launches
+  if (h->sgs_graph_exec) { hipGraphExecDestroy(h->sgs_graph_exec); h->sgs_graph_exec = nullptr; }
   return GSM_OK;
 }
 

@@ -181,6 +181,8 @@ struct SgsArgs {
   const double* ys;        // [H] y coordinate of every row
   const double* lag;       // [(2 mi + 1) * (2 mj + 1)] covariance at integer lag (di, dj), |di| <= mi, |dj| <= mj
   int hw, mi, mj, num_points;
+  int ktype;               // 0 ordinary kriging (ok_solve), 1 simple kriging (sk_solve) with gmean
+  const double* gmean;     // [n_chains] global mean of each chain's conditioning values (simple kriging only)
   double radius, sill;
   const int32_t* cell_off; // [n_chains+1] (or [n_chains] with cell_cnt)
   const int32_t* cell_cnt; // optional [n_chains]: number of cells of each chain

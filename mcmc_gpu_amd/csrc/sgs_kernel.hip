@@ -153,8 +153,8 @@ template <int K>
 struct GjStep {
   // one Gauss-Jordan step on pivot K: r[] is this lane's row of [A | b] (columns 0..47 neighbours, 48 the Lagrange column,
   // 49 the right-hand side)
-  static __device__ __forceinline__ void run(double (&r)[50], int lane, int n, double tol, double tol_l, double& mypiv, bool& singular) {
-    if (K < n || K == 48) {                                      // wave-uniform: rows n..47 do not exist
+  static __device__ __forceinline__ void run(double (&r)[50], int lane, int n, bool lagr, double tol, double tol_l, double& mypiv, bool& singular) {
+    if (K < n || (K == 48 && lagr)) {                            // wave-uniform: rows n..47 do not exist; no Lagrange row in simple kriging
       const dev::v2i32 pb = __builtin_bit_cast(dev::v2i32, r[K]);
       dev::v2i32 ps;
       ps.x = __builtin_amdgcn_readlane(pb.x, K);
@@ -176,12 +176,12 @@ struct GjStep {
         r[j] = __fma_rn(-f, __builtin_bit_cast(double, o), r[j]);
       }
     }
-    GjStep<K + 1>::run(r, lane, n, tol, tol_l, mypiv, singular);
+    GjStep<K + 1>::run(r, lane, n, lagr, tol, tol_l, mypiv, singular);
   }
 };
 template <>
 struct GjStep<49> {
-  static __device__ __forceinline__ void run(double (&)[50], int, int, double, double, double&, bool&) {}
+  static __device__ __forceinline__ void run(double (&)[50], int, int, bool, double, double, double&, bool&) {}
 };
 
 __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
@@ -318,7 +318,9 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
   }
   if (lane < n) { const int gg = L.nb_g[lane]; const int rr = gg / W; L.nb_rc[lane] = (rr << 16) | (gg - rr * W); }
   __syncthreads();
-  // ---- ordinary kriging system, one row per lane in registers ----------------------------------------------------------
+  // ---- kriging system, one row per lane in registers: ordinary kriging [Sigma 1; 1' 0] w = [rho; 1] (_krige.py:25-37) or, with
+  // a.ktype == 1, simple kriging Sigma w = rho (_krige.py:66-73: no Lagrange row / column) ------------------------------------
+  const bool lagr = a.ktype == 0;
   const int mi = a.mi, mj = a.mj, lag_w = 2 * mj + 1;
   const double* __restrict__ lag = a.lag;
   double r[50];
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
         const int rc = L.nb_rc[j];
         const int di = my_i - (rc >> 16), dj = my_j - (rc & 0xFFFF);
         if (abs(di) > mi || abs(dj) > mj) lag_ok = false; else v = lag[(di + mi) * lag_w + dj + mj];
-      } else if (lane == 48) v = 1.0;
+      } else if (lane == 48 && lagr) v = 1.0;
     }
     r[j] = v;
   }
@@ -341,9 +343,9 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
     double v48 = 0.0, v49 = 0.0;
     if (lane < n) {
       const int di = my_i - i0, dj = my_j - j0;
-      v48 = 1.0;
+      v48 = lagr ? 1.0 : 0.0;
       if (abs(di) > mi || abs(dj) > mj) lag_ok = false; else v49 = lag[(di + mi) * lag_w + dj + mj];
-    } else if (lane == 48) v49 = 1.0;
+    } else if (lane == 48 && lagr) v49 = 1.0;
     r[48] = v48; r[49] = v49;
   }
   if (__ballot(!lag_ok)) { if (lane == 0) { atomicOr(a.err, 64); a.rec_hdr[rec].n = 0; a.rec_hdr[rec].op = (i0 - r0) * ww + (j0 - c0); } return; }
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
   const double tol = 2.220446049250313e-16 * (double)(n + 1) * fabs(c00), tol_l = 2.220446049250313e-16 * (double)(n + 1) / fabs(c00);
   double mypiv = 1.0;
   bool singular = false;
-  GjStep<0>::run(r, lane, n, tol, tol_l, mypiv, singular);
+  GjStep<0>::run(r, lane, n, lagr, tol, tol_l, mypiv, singular);
   if (singular) {
     if (lane == 0) { atomicOr(a.err, 8); a.rec_hdr[rec].n = 0; a.rec_hdr[rec].op = (i0 - r0) * ww + (j0 - c0); }
     return;
@@ -380,7 +382,10 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
   }
   if (lane == 0) {
     SgsCellHdr hd;
-    hd.n = n; hd.op = (i0 - r0) * ww + (j0 - c0); hd.sdz = sqrt(var) * a.z[k_lo + slot]; hd.var = var; hd.c1 = (1.0 - sw) / (double)n;
+    hd.n = n; hd.op = (i0 - r0) * ww + (j0 - c0); hd.sdz = sqrt(var) * a.z[k_lo + slot]; hd.var = var;
+    // ordinary: est = local mean + sum w (v - local mean) (_krige.py:42) -> c1 = (1 - sum w) / n multiplies sum v;
+    // simple:   est = global mean + sum w (v - global mean) (_krige.py:79) -> c1 = global mean * (1 - sum w) is added as it is
+    hd.c1 = lagr ? (1.0 - sw) / (double)n : a.gmean[chain] * (1.0 - sw);
     a.rec_hdr[rec] = hd;
   }
 }
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(64) void sgs_sequence_kernel(const SgsArgs a) {
       // DPP latency instead of two in a row on the chain's critical path), c1 = (1 - sum w) / n comes with the record
       double sv = v_l, swv = w_l * v_l;
       wave_sum2_f64(sv, swv);
-      const double est = swv + sv * c1;
+      const double est = swv + (a.ktype == 0 ? sv * c1 : c1);
       if (lane == 0) {
         overlay[op] = est + sdz;
         if (a.trace) { a.trace[3 * (k_lo + k)] = (double)n; a.trace[3 * (k_lo + k) + 1] = est; a.trace[3 * (k_lo + k) + 2] = var; }

@@ -2,7 +2,7 @@
 
     chain_sgs                      gstatsMCMC/MCMC.py:1445-1911   -> chain_sgs_gpu
     init_msc_chain_by_instance     gstatsMCMC/MCMC.py:402-431
-    sgs / neighbors / ok_solve     MCMC.py:91-173, gstatsim_custom/neighbors.py:4-64, _krige.py:5-44  -> gsm_sgs_blocks (HIP)
+    sgs / neighbors / ok_solve / sk_solve   MCMC.py:91-173, gstatsim_custom/neighbors.py:4-64, _krige.py:5-81  -> sgs, gsm_sgs_blocks (HIP)
 
 Same class / setter names, argument meaning and return tuple as the reference.  Per iteration the host draws what the
 reference draws from the chain's NumPy generator, in its order (block centre by rejection, block sizes, the shuffle of
@@ -32,7 +32,7 @@ from copy import deepcopy
 
 import numpy as np
 
-__all__ = ["chain_sgs_gpu", "init_msc_chain_by_instance", "run_many_sgs", "cov_norm", "lag_cov_table"]
+__all__ = ["chain_sgs_gpu", "init_msc_chain_by_instance", "run_many_sgs", "sgs", "cov_norm", "lag_cov_table"]
 
 
 def cov_norm(h, vtype, sill, nugget, s=None):
@@ -93,6 +93,90 @@ def _axes(xx, yy):
     if not (np.allclose(np.diff(xs), dx, rtol=1e-9, atol=0) and np.allclose(np.diff(ys), dy, rtol=1e-9, atol=0)):
         raise NotImplementedError("the device SGS needs uniform grid spacing")
     return xs, ys, float(dx), float(dy)
+
+
+def sgs(xx, yy, grid, variogram, radius=100e3, num_points=20, ktype='ok', sim_mask=None, quiet=False, stencil=None, rcond=None,
+        seed=None, device=None):
+    """Sequential Gaussian simulation with ordinary ('ok') or simple ('sk') kriging -- the reference's module-level MCMC.sgs
+    (MCMC.py:91-173 with _preprocess :42-88), same arguments and return value, executed by gsm_sgs_blocks.  The generator is
+    consumed exactly as the reference consumes it: one shuffle of the cells of sim_mask, then one normal per simulated cell.
+    Limits of the device path (NotImplementedError otherwise): the NaN cells to simulate lie within one window of at most 1024
+    cells (the small-scale chain's blocks; MCMC.py:1762-1774), the circular search stencil and lstsq's default rcond,
+    scalar variogram parameters, 8 <= num_points <= 48, an axis-aligned uniform grid."""
+    import torch
+    from .engine import GsmEngine
+    for name, a in (("xx", xx), ("yy", yy), ("grid", grid)):
+        if not isinstance(a, np.ndarray) or a.ndim != 2:
+            raise ValueError(f"{name} must be a 2D NumPy array")                  # _sanity_checks, interpolate.py:282-298
+    if xx.shape != yy.shape or xx.shape != grid.shape:
+        raise ValueError("xx, yy, and grid must have same shape")
+    for key in ("major_range", "minor_range", "azimuth", "sill", "nugget", "vtype"):
+        if key not in variogram:
+            raise ValueError(f"Missing variogram parameter {key}")
+    if variogram["vtype"].lower() == "matern" and "s" not in variogram:
+        raise ValueError("Missing variogram parameter s for Matern covariance")
+    if ktype not in ("ok", "sk"):
+        raise ValueError("ktype must be 'ok' or 'sk'")
+    if stencil is not None or rcond is not None:
+        raise NotImplementedError("the device SGS searches the circular stencil and solves with lstsq's default cut-off (rcond=None)")
+    if any(not isinstance(variogram[k], (int, float, np.integer, np.floating)) for k in variogram if k != "vtype"):
+        raise NotImplementedError("the device SGS takes scalar variogram parameters (one covariance table per call)")
+    if not 8 <= int(num_points) <= 48:
+        raise NotImplementedError("the device SGS takes 8 <= num_points <= 48")
+    if seed is None:                                                                  # utilities.get_random_generator, :50-70
+        rng = np.random.default_rng()
+    elif isinstance(seed, int):
+        rng = np.random.default_rng(seed=seed)
+    elif isinstance(seed, np.random.Generator):
+        rng = seed
+    else:
+        raise ValueError("Seed should be an integer, a NumPy random Generator, or None")
+    grid = np.asarray(grid, dtype=np.float64)
+    H, W = grid.shape
+    cond_msk = ~np.isnan(grid)
+    if sim_mask is None:
+        sim_mask = np.full(xx.shape, True)
+    ii, jj = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    inds = np.array([ii[sim_mask].flatten(), jj[sim_mask].flatten()]).T
+    global_mean = np.mean(grid[cond_msk])                                          # MCMC.py:81
+    rng.shuffle(inds)                                                                 # MCMC.py:128
+    need = ~cond_msk[inds[:, 0], inds[:, 1]] if inds.shape[0] else np.zeros(0, bool)
+    todo = inds[need]
+    out = grid.copy()
+    if todo.shape[0] == 0:
+        return out
+    r0, r1, c0, c1 = int(todo[:, 0].min()), int(todo[:, 0].max()) + 1, int(todo[:, 1].min()), int(todo[:, 1].max()) + 1
+    if (r1 - r0) * (c1 - c0) > 1024:
+        raise NotImplementedError("the device SGS simulates one block: the cells to simulate must fit a window of at most 1024 cells")
+    # listed cells: the cells to simulate in visiting order, then every other window cell that holds a value (conditioning data:
+    # never simulated, seen by the search from the start); a window cell that stays NaN is not listed
+    inside = np.zeros((H, W), bool); inside[r0:r1, c0:c1] = True
+    todo_m = np.zeros((H, W), bool); todo_m[todo[:, 0], todo[:, 1]] = True
+    rest = np.argwhere(inside & cond_msk & ~todo_m)
+    cells = np.ascontiguousarray(np.concatenate([todo, rest]), dtype=np.int32)
+    z = np.zeros(cells.shape[0])
+    z[:todo.shape[0]] = rng.standard_normal(todo.shape[0])                           # rng.normal(est, sd, 1) = est + sd * normal, :165
+    xs, ys, dx, dy = _axes(np.asarray(xx, dtype=np.float64), np.asarray(yy, dtype=np.float64))
+    vario = {k: (variogram[k] if k == "vtype" else float(variogram[k])) for k in variogram}
+    hw = int(math.ceil(float(radius) / abs(dx)))
+    eng = GsmEngine(H, W, 1, device)
+    try:
+        dev, lib, h = eng.dev, eng.lib, eng.h
+        f64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+        mi, mj = lag_extents(hw, H, W)
+        d_grid, d_xs, d_ys, d_lag = f64(grid[None]), f64(xs), f64(ys), f64(lag_cov_table(vario, hw, dx, dy, mi, mj))
+        d_win, d_off, d_cells, d_z = i32([[r0, r1, c0, c1]]), i32([0, cells.shape[0]]), i32(cells), f64(z)
+        d_gm = f64([global_mean])
+        with torch.cuda.device(dev):
+            eng._check(lib.gsm_sgs_set_kriging(h, 1 if ktype == "sk" else 0, _ptr(d_gm)))
+            eng._check(lib.gsm_sgs_blocks(h, _ptr(d_grid), None, _ptr(d_win), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), mi, mj, hw, float(radius),
+                                          int(num_points), float(vario["sill"]), _ptr(d_off), _ptr(d_cells), _ptr(d_z), int(cells.shape[0]),
+                                          None, None, eng._stream()))
+        out = d_grid[0].cpu().numpy()
+    finally:
+        eng.close()
+    return out
 
 
 class chain_sgs_gpu:

@@ -135,3 +135,35 @@ def driver_chain(prob, trend, nst, seed, vario_param=None, sgs_param=None, block
     ch.set_sgs_param(sp[0], sp[1], sgs_rand_dropout_on=False)
     ch.set_random_generator(rng_seed=seed)
     return ch
+
+
+# ---- golden F12: the reference's module-level MCMC.sgs with ordinary and simple kriging (oracle/make_fixtures_r3b.py) -------------
+GOLD12 = ROOT / "tests" / "golden" / "f12_sgs_function_ok_sk.npz"
+F12_CASES = ("ok", "sk", "skm")
+
+
+def f12_case(tag):
+    """(xx, yy, grid, variogram, keyword arguments of MCMC.sgs, seed) of F12 case `tag`: the standardised synthetic bed of a
+    48 x 48 tie-free grid with a 13 x 16 block of NaN cells crossed by two conditioning lines."""
+    H = 48
+    prob = orc.synthetic_problem(H, res=500.0)
+    xx = np.ascontiguousarray(prob["xx"], dtype=np.float64)
+    yy = np.ascontiguousarray(np.broadcast_to((np.arange(H) * TIE_FREE_DY)[:, None], (H, H)), dtype=np.float64)
+    grid = (prob["bed"] - prob["bed"].mean()) / prob["bed"].std()
+    hole = np.zeros((H, H), bool)
+    hole[17:30, 9:25] = True
+    hole[22, :] = False                     # conditioning lines through the block
+    hole[:, 14] = False
+    grid = np.where(hole, np.nan, grid)
+    if tag == "ok":
+        vario = dict(azimuth=0, nugget=0, major_range=9000.0, minor_range=9000.0, sill=1.0, vtype="Exponential")
+        return xx, yy, grid, vario, dict(radius=10e3), 1201
+    if tag == "sk":
+        vario = dict(azimuth=0, nugget=0, major_range=11000.0, minor_range=11000.0, sill=1.0, vtype="Matern", s=1.3)
+        return xx, yy, grid, vario, dict(radius=12e3, num_points=32, ktype="sk"), 1202
+    if tag == "skm":
+        vario = dict(azimuth=35.0, nugget=0.05, major_range=14000.0, minor_range=7000.0, sill=1.3, vtype="Spherical")
+        sim_mask = np.zeros((H, H), bool)
+        sim_mask[17:30, 9:19] = True        # the rest of the NaN block is not simulated
+        return xx, yy, grid, vario, dict(radius=8e3, num_points=16, ktype="sk", sim_mask=sim_mask), 1203
+    raise KeyError(tag)

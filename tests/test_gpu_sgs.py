@@ -407,3 +407,26 @@ def test_graph_replay_of_a_batch_equals_the_eager_launches(monkeypatch, transfor
     for x, y in zip(a, b):
         for k in (0, 3, 4, 5, 6):
             assert np.array_equal(np.asarray(x[k], dtype=float), np.asarray(y[k], dtype=float), equal_nan=True), k
+
+
+@pytest.mark.parametrize("tag", ["ok", "sk", "skm"])
+def test_sgs_function_ok_and_sk_equal_reference_fixture(tag):
+    """Golden F12: the reference's module-level MCMC.sgs (MCMC.py:91-173) with ordinary and simple kriging (_krige.py:5-44, :46-81;
+    gsm_sgs_set_kriging) on a tie-free grid.  Same generator consumption (final state identical), same NaN cells, simulated values
+    to 1e-8 absolute on standardised values (lstsq vs elimination, values feeding on each other cell after cell)."""
+    from mcmc_gpu_amd import sgs
+    g = np.load(sc.GOLD12, allow_pickle=False)
+    xx, yy, grid, vario, kw, seed = sc.f12_case(tag)
+    rng = np.random.default_rng(seed)
+    out = sgs.sgs(xx, yy, grid.copy(), dict(vario), seed=rng, **kw)
+    exp = g[f"{tag}_out"]
+    assert rng.bit_generator.state == json.loads(str(g[f"{tag}_rng_state"]))
+    assert np.array_equal(np.isnan(out), np.isnan(exp))
+    keep = ~np.isnan(grid)
+    assert np.array_equal(out[keep], grid[keep])                              # conditioning values untouched
+    new = np.isnan(grid) & ~np.isnan(exp)
+    assert new.sum() == int(g[f"{tag}_n_sim"])
+    np.testing.assert_allclose(out[new], exp[new], rtol=0, atol=1e-8)
+    if tag != "ok":                                                           # simple != ordinary kriging on this problem
+        other = sgs.sgs(xx, yy, grid.copy(), dict(vario), seed=np.random.default_rng(seed), **dict(kw, ktype="ok"))
+        assert np.abs(other[new] - out[new]).max() > 1e-3

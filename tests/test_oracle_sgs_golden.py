@@ -135,3 +135,20 @@ def test_sgs_oracle_reproduces_driver_config_fixture(tag):
     assert hashlib.sha256(np.ascontiguousarray(tr).tobytes()).hexdigest() == str(g[f"{tag}_trace_sha"])
     if tag == "b":
         assert tr[:, 2].min() >= 1                         # the widened search found something for every cell
+
+
+@pytest.mark.parametrize("tag", ["ok", "sk", "skm"])
+def test_sgs_function_oracle_reproduces_reference_fixture_ok_and_sk(tag):
+    """Golden F12 (oracle/make_fixtures_r3b.py): the reference's module-level MCMC.sgs with ktype 'ok' and 'sk' (_krige.py:5-81)
+    on a tie-free grid; the restatement must give the same grid bit for bit and leave the generator in the same state."""
+    import sgs_common as sc
+    g = np.load(sc.GOLD12, allow_pickle=False)
+    xx, yy, grid, vario, kw, seed = sc.f12_case(tag)
+    rng = np.random.default_rng(seed)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = so.sgs(xx, yy, grid.copy(), dict(vario), rng=rng, **kw)
+    assert np.array_equal(out, g[f"{tag}_out"], equal_nan=True)
+    assert rng.bit_generator.state == json.loads(str(g[f"{tag}_rng_state"]))
+    assert int(np.isnan(grid).sum() - np.isnan(out).sum()) == int(g[f"{tag}_n_sim"]) > 100

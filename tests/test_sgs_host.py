@@ -74,3 +74,28 @@ def test_sgs_entries_are_exported_and_setters_validate():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):
             ch.run(3, only_save_last_bed=True, plot=False, progress_bar=None)      # no CPU fallback
+
+
+def test_sgs_function_argument_errors_are_the_references():
+    """mcmc_gpu_amd.sgs.sgs mirrors MCMC.sgs (MCMC.py:91): the reference's _sanity_checks / get_random_generator errors
+    (interpolate.py:282-330, utilities.py:62-69) are raised before anything touches the device; what the device path does not
+    cover is a NotImplementedError, never a silent CPU computation."""
+    xx, yy, grid, vario, kw, seed = sc.f12_case("sk")
+    with pytest.raises(ValueError):
+        sgs.sgs(xx, yy, grid[0], vario, **kw)                                  # grid must be 2D
+    with pytest.raises(ValueError):
+        sgs.sgs(xx, yy[:-1], grid, vario, **kw)                                # same shapes
+    with pytest.raises(ValueError):
+        sgs.sgs(xx, yy, grid, {k: v for k, v in vario.items() if k != "sill"}, **kw)
+    with pytest.raises(ValueError):
+        sgs.sgs(xx, yy, grid, vario, **dict(kw, ktype="uk"))
+    with pytest.raises(ValueError):
+        sgs.sgs(xx, yy, grid, vario, seed="seed", **kw)
+    with pytest.raises(NotImplementedError):
+        sgs.sgs(xx, yy, grid, vario, stencil=np.ones((3, 3), bool), **kw)
+    with pytest.raises(NotImplementedError):
+        sgs.sgs(xx, yy, grid, vario, **dict(kw, num_points=64))
+    with pytest.raises(NotImplementedError):
+        sgs.sgs(xx, yy, np.full(grid.shape, np.nan), vario, seed=1, **kw)      # 2304 cells to simulate: not one block
+    full = np.where(np.isnan(grid), 0.0, grid)
+    assert np.array_equal(sgs.sgs(xx, yy, full, vario, seed=1, **kw), full)    # nothing to simulate: the grid comes back
