@@ -530,7 +530,9 @@ __global__ __launch_bounds__(64) void sgs_loss_finish_kernel(int n_chains, int p
   bad[c] = nb;
 }
 
-int sgs_loss_parts(const StaticFields& S) { return std::max(1, std::min(64, (S.H * S.W + 4095) / 4096)); }
+// parts of a chain's map: a function of the grid alone (a chain's loss must not depend on how many chains share the handle);
+// ~1024 cells each, so that a few chains still spread over the chip (4 chains at 64 x 64: +6 % per iteration against 4096)
+int sgs_loss_parts(const StaticFields& S) { return std::max(1, std::min(64, (S.H * S.W + 1023) / 1024)); }
 
 hipError_t launch_sgs_loss(const StaticFields& S, int n_chains, const double* beds, const double* trend, double* loss, int32_t* bad,
                            double* part_sum, int32_t* part_bad, hipStream_t st) {
