@@ -430,3 +430,57 @@ def test_sgs_function_ok_and_sk_equal_reference_fixture(tag):
     if tag != "ok":                                                           # simple != ordinary kriging on this problem
         other = sgs.sgs(xx, yy, grid.copy(), dict(vario), seed=np.random.default_rng(seed), **dict(kw, ktype="ok"))
         assert np.abs(other[new] - out[new]).max() > 1e-3
+
+
+def _max_block_setup(block_min, block_max):
+    from mcmc_gpu_amd import sgs
+    H = 64
+    prob = sc.orc.synthetic_problem(H, res=500.0)
+    prob["yy"] = np.ascontiguousarray(np.broadcast_to((np.arange(H) * sc.TIE_FREE_DY)[:, None], (H, H)))
+    data_mask = np.zeros((H, H), dtype=bool); data_mask[::8, :] = True; data_mask[:, ::16] = True
+    cond = np.where(data_mask, prob["bed"], np.nan)
+    grounded = np.ones((H, H), dtype=int)
+    sill = float(np.var(prob["bed"]))
+    region = np.zeros((H, H), dtype=int); region[17:47, 17:47] = 1            # block centres: no block of <= 32 cells is clipped
+    vp = [0, 0.0, 6000.0, 6000.0, sill, "Exponential", None]
+    cfg = so.SgsConfig(prob["xx"], prob["yy"], prob["surf"], prob["velx"], prob["vely"], prob["dhdt"], prob["smb"], cond, data_mask,
+                       grounded, region, prob["resolution"], 5000.0, vp, [16, 4000.0, False, 0], block_min, block_max, block_min, block_max)
+    ch = sgs.chain_sgs_gpu(prob["xx"], prob["yy"], prob["bed"], prob["surf"], prob["velx"], prob["vely"], prob["dhdt"], prob["smb"],
+                           cond, data_mask, grounded, prob["resolution"])
+    ch.set_update_region(True, region)
+    ch.set_loss_type(sigma_mc=5000.0, massConvInRegion=True)       # flat posterior: proposals are accepted, their values recorded
+    ch.set_normal_transformation(None, do_transform=False)
+    ch.set_trend(None, detrend_map=False)
+    ch.set_variogram("Exponential", 6000.0, sill, 0.0, isotropic=True)
+    ch.set_sgs_param(16, 4000.0)
+    ch.set_block_sizes(block_min, block_max, block_min, block_max)
+    return prob, cfg, ch
+
+
+@pytest.mark.parametrize("mode", ["replay", "pcg64"])
+def test_largest_blocks_the_device_takes_equal_the_oracle(mode):
+    """Block size 32 in both directions (rng.integers(32, 33)): every window is 32 x 32 = 1024 cells, the most one block simulation
+    holds (window and record buffers of sgs_kernel.hip) -- against the oracle on the same generator, with host draws and with
+    the generator advanced on the device."""
+    prob, cfg, ch = _max_block_setup(32, 33)
+    n_iter = 4
+    rng_o = np.random.default_rng(seed=314)
+    ref = so.run_chain_sgs(cfg, prob["bed"], n_iter, rng_o)
+    ch.set_random_generator(rng_seed=314)
+    ch.set_rng_mode(mode)
+    out = ch.run(n_iter, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None)
+    assert np.array_equal(out[6], ref[6]) and np.array_equal(out[4], ref[4]) and np.array_equal(out[5], ref[5])
+    assert np.all(ref[6][1:, 2] * ref[6][1:, 3] == 1024) and ref[5].max() >= 1
+    np.testing.assert_allclose(out[3], ref[3], rtol=1e-9)
+    np.testing.assert_allclose(out[0], ref[0], rtol=0, atol=1e-7)
+    assert ch.rng.bit_generator.state == rng_o.bit_generator.state
+
+
+def test_blocks_beyond_the_device_limit_are_refused():
+    """A block of more than 1024 cells does not fit one block simulation: the call ends with the library's error, not with a
+    wrong bed (block sizes up to 40 -> windows up to 39 x 39)."""
+    from mcmc_gpu_amd._lib import GsmError
+    prob, cfg, ch = _max_block_setup(36, 41)
+    ch.set_random_generator(rng_seed=1)
+    with pytest.raises(GsmError):
+        ch.run(3, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None)
