@@ -131,6 +131,27 @@ __device__ __forceinline__ double log1p_fdlibm(double x) {
   return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
 }
 
+// A tail start (idx == 0 on the slow path: about 1 normal in 3 700) at the head of the stream, in uniform code with sequential
+// draws: pairs of uniforms until yy + yy > xx * xx (random_standard_normal's tail loop, libm's log1p restated).  Out of line -- one
+// copy in the kernel -- and by value: a member function would take the stream's address and put its state into scratch memory.
+struct TailDraw { double val; u128 s; };
+__device__ __noinline__ inline TailDraw tail_normal(u128 s, u128 inc) {
+  const double zr = 3.6541528853610087963519472518, zinv = 0.27366123732975827203338247596;
+  const u128 M{kMultLo, kMultHi};
+  s = add128(mul128(M, s), inc);
+  const uint64_t raw0 = output_xsl_rr(s);
+  const uint64_t rabs0 = ((raw0 >> 8) >> 1) & 0x000fffffffffffffull;
+  for (;;) {
+    s = add128(mul128(M, s), inc);
+    const double u1 = to_double(output_xsl_rr(s));
+    s = add128(mul128(M, s), inc);
+    const double u2 = to_double(output_xsl_rr(s));
+    const double xx = -zinv * log1p_fdlibm(-u1);
+    const double yy = -log1p_fdlibm(-u2);
+    if (yy + yy > xx * xx) return TailDraw{((rabs0 >> 8) & 1) ? -(zr + xx) : zr + xx, s};
+  }
+}
+
 // One generator stream held by a wavefront (every lane holds the same values: uniform code).
 struct Stream {
   u128 s, inc;            // LCG state (before the next draw) and increment
@@ -206,7 +227,6 @@ struct Stream {
   // before a tail start (resolved in uniform code at the head of the next window) and before a wedge start in lane 63 (its
   // uniform is the next window's draw).  The state behind the consumed draws is the one a lane already holds (v_readlane).
   __device__ __forceinline__ void normals(int count, double loc, double scale, double* dst, int lane, u128 A_l, u128 C_l) {
-    const double zr = 3.6541528853610087963519472518, zinv = 0.27366123732975827203338247596;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int rank = 0;
     while (rank < count) {
@@ -215,36 +235,29 @@ struct Stream {
       const int idx = (int)(raw & 0xff);
       const uint64_t r8 = raw >> 8;
       const uint64_t rabs = (r8 >> 1) & 0x000fffffffffffffull;
-      double x = (double)rabs * __builtin_bit_cast(double, zig[256 + idx]);
+      // (double)rabs, rabs < 2^52: the integer sits in the mantissa of 2^52 + rabs (exact)
+      double x = (__builtin_bit_cast(double, 0x4330000000000000ull | rabs) - 4503599627370496.0) * __builtin_bit_cast(double, zig[256 + idx]);
       if (r8 & 1) x = -x;
       const bool slow = !(rabs < zig[idx]);
-      const unsigned long long slow_mask = __ballot(slow), tail_mask = __ballot(slow && idx == 0);
+      const unsigned long long slow_mask = __ballot(slow);
+      const int need = count - rank;
+      if (slow_mask == 0ull) {
+        // ---- all 64 draws take the fast path (64 % of the windows): 64 normals, 64 draws -- or the rest of the plane ----------
+        if (lane < need && dst) dst[rank + lane] = loc + scale * x;
+        const int used = min(64, need);
+        rank += used;
+        s = lane_state(st, used);
+        continue;
+      }
+      const unsigned long long tail_mask = __ballot(slow && idx == 0);
       if (tail_mask & 1ull) {
-        // ---- the window begins with a tail start: uniform code (about 1 normal in 3 700) -------------------------------
-        auto raw_at = [&](int pos1) -> uint64_t {                           // the draw pos1 positions ahead of `s` (1 .. 64)
-          return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)raw, pos1 - 1) |
-                 ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(raw >> 32), pos1 - 1) << 32);
-        };
-        const uint64_t raw0 = raw_at(1);
-        const uint64_t rabs0 = ((raw0 >> 8) >> 1) & 0x000fffffffffffffull;
-        int pos = 1;
-        double val = 0.0;
-        bool produced = false;
-        while (pos + 2 <= 64) {
-          const double u1 = to_double(raw_at(pos + 1)), u2 = to_double(raw_at(pos + 2));
-          pos += 2;
-          const double xx = -zinv * log1p_fdlibm(-u1);
-          const double yy = -log1p_fdlibm(-u2);
-          if (yy + yy > xx * xx) { val = ((rabs0 >> 8) & 1) ? -(zr + xx) : zr + xx; produced = true; break; }
-        }
-        s = lane_state(st, pos);
-        while (!produced) {                                                 // > 31 rejected pairs in a row: never in practice
-          const double u1 = next_double(), u2 = next_double();
-          const double xx = -zinv * log1p_fdlibm(-u1);
-          const double yy = -log1p_fdlibm(-u2);
-          if (yy + yy > xx * xx) { val = ((rabs0 >> 8) & 1) ? -(zr + xx) : zr + xx; produced = true; }
-        }
-        if (lane == 0 && dst) dst[rank] = loc + scale * val;
+        const TailDraw td = tail_normal(s, inc);
+        // a call returns in vector registers: back to scalar ones, or every later use of the state becomes vector code
+        s.lo = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)td.s.lo) |
+               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(td.s.lo >> 32)) << 32);
+        s.hi = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)td.s.hi) |
+               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(td.s.hi >> 32)) << 32);
+        if (lane == 0 && dst) dst[rank] = loc + scale * td.val;
         rank += 1;
         continue;
       }
@@ -258,7 +271,7 @@ struct Stream {
       const unsigned long long cut = (tail_mask & start_mask) | wedge63;
       const int limit = cut ? (__ffsll((long long)cut) - 1) : 64;           // >= 1: lane 0 is a start and neither cut case
       const bool is_start = ((start_mask >> lane) & 1ull) && lane < limit;
-      // the uniform of a wedge start is the next lane's draw
+      // the uniform of a wedge start is the next lane's draw (all lanes active here: the exchange reads live lanes)
       const uint64_t raw_next = (uint64_t)(uint32_t)__shfl_down((int)(uint32_t)raw, 1, 64) |
                                 ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(raw >> 32), 1, 64) << 32);
       bool produced = is_start && !slow;
@@ -267,7 +280,7 @@ struct Stream {
         produced = (f0 - f1) * to_double(raw_next) + f1 < exp(-0.5 * x * x);
       }
       const unsigned long long pmask = __ballot(produced);
-      const int need = count - rank, got = __popcll(pmask);
+      const int got = __popcll(pmask);
       const int my = __popcll(pmask & below);
       if (produced && my < need && dst) dst[rank + my] = loc + scale * x;
       int consumed = limit;

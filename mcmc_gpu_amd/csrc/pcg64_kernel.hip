@@ -40,9 +40,13 @@ __global__ __launch_bounds__(64) void pcg64_draw_kernel(const PcgDrawArgs a) {
     double rx, ry;
     if (!P.isotropic) { rx = R.uniform(P.range_min_x, P.range_max_x); ry = R.uniform(P.range_min_y, P.range_max_y); }
     else { rx = R.uniform(P.range_min_x, P.range_max_x); ry = rx; }
-    R.normals(B, 0.0, 1.0, a.noise_re + rec * a.field_stride, lane, A_l, C_l);
-    R.normals(B, 0.0, 1.0, a.noise_im + rec * a.field_stride, lane, A_l, C_l);
-    R.normals(B, 0.0, sqrt(nug), a.nugget ? a.nugget + rec * a.field_stride : nullptr, lane, A_l, C_l);
+    // the three planes of a step (MCMC.py:242 twice, :251) through ONE copy of the window loop
+#pragma nounroll
+    for (int pl = 0; pl < 3; ++pl) {
+      double* dst = (pl == 0) ? a.noise_re + rec * a.field_stride : (pl == 1) ? a.noise_im + rec * a.field_stride
+                                                                              : (a.nugget ? a.nugget + rec * a.field_stride : nullptr);
+      R.normals(B, 0.0, (pl == 2) ? sqrt(nug) : 1.0, dst, lane, A_l, C_l);
+    }
     int ix = 0, iy = 0;
     for (int tries = 0;; ++tries) {
       ix = (int)C.bounded((uint32_t)a.H);
