@@ -68,8 +68,15 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_f64(double x) {
   const v2i32 b = __builtin_bit_cast(v2i32, x);
   v2i32 o;
-  o.x = __builtin_amdgcn_update_dpp(0, b.x, CTRL, ROW_MASK, 0xF, false);
-  o.y = __builtin_amdgcn_update_dpp(0, b.y, CTRL, ROW_MASK, 0xF, false);
+  if constexpr (ROW_MASK == 0xF) {
+    // every lane is written and (quad_perm / row_mirror / row_half_mirror) has a source: no "old" value to initialise -- with
+    // update_dpp(0, ...) the compiler zeroes the destination pair before each of these moves
+    o.x = __builtin_amdgcn_mov_dpp(b.x, CTRL, 0xF, 0xF, true);
+    o.y = __builtin_amdgcn_mov_dpp(b.y, CTRL, 0xF, 0xF, true);
+  } else {
+    o.x = __builtin_amdgcn_update_dpp(0, b.x, CTRL, ROW_MASK, 0xF, false);
+    o.y = __builtin_amdgcn_update_dpp(0, b.y, CTRL, ROW_MASK, 0xF, false);
+  }
   return __builtin_bit_cast(double, o);
 }
 // sum over the 16 lanes of a DPP row; every lane of the row ends with the same value
