@@ -442,6 +442,7 @@ __global__ __launch_bounds__(64) void sgs_sequence_kernel(const SgsArgs a) {
       const int q = k - kc;
       const double4 hraw = *(const double4*)(st + kSeqVwDoubles + 4 * q);
       const double2 v0 = *(const double2*)(st + (q * kSgsMaxPts + ln) * 2);
+      lds_order();                    // both reads in flight together (else the neighbour read sinks below the header's branches: a second LDS round trip)
       const uint64_t nop = __builtin_bit_cast(uint64_t, hraw.x);
       const int n = __builtin_amdgcn_readfirstlane((int)(uint32_t)nop), op = __builtin_amdgcn_readfirstlane((int)(nop >> 32));
       const double sdz = hraw.y, var = hraw.z, c1 = hraw.w;
