@@ -440,9 +440,6 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
         if pcg64:
             d_gen = torch.as_tensor(GsmEngine.pack_pcg64_states(list(rngs)).view(np.int64)).to(dev)
         philox = philox or pcg64          # both draw on the device: same loop below
-        if philox and host_nst is not None:
-            raise NotImplementedError("Philox mode of the small-scale chain keeps the whole iteration on the device: the normal-score "
-                                      "transformer must be scikit-learn's QuantileTransformer (normal output, one feature) or absent")
         batch = int(os.environ.get('GSM_SGS_BATCH', '32')) if (host_nst is None and not keep_all and not track) else 1
         if philox:
             if not pcg64:
@@ -489,7 +486,8 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
             d_lprev = f64(loss_prev); d_acc = torch.empty(n, dtype=torch.uint8, device=dev)
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
-        while philox and it_done < n_iter:
+        # (a transformer of another kind than scikit-learn's is called on the host once per iteration: the loop further down)
+        while philox and host_nst is None and it_done < n_iter:
             kb = min(batch, n_iter - it_done)
             d_win, d_blk, d_off, d_cnt = b_win[:kb * n * 4].view(kb, n, 4), b_blk[:kb * n * 4].view(kb, n, 4), b_off[:kb * n].view(kb, n), b_cnt[:kb * n].view(kb, n)
             d_us = b_us[:kb * n].view(kb, n)
@@ -588,27 +586,47 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
                 it_done += running['kb']
             finish(running)
         for it in range(it_done, n_iter):
-            wins = np.empty((n, 4), np.int32); offs = np.zeros(n + 1, np.int32); us = np.empty(n)
-            cells, zs = [], []
-            for c in range(n):
-                blk, win, inds, z, us[c] = chain._draw_iteration(rngs[c], cond_is_data)
-                blocks_cache[c, it] = blk
-                wins[c] = win
-                cells.append(inds); zs.append(z)
-                offs[c + 1] = offs[c] + inds.shape[0]
-            d_win = torch.as_tensor(wins).to(dev)
-            d_off = torch.as_tensor(offs).to(dev)
-            d_cells = torch.as_tensor(np.ascontiguousarray(np.concatenate(cells) if offs[-1] else np.zeros((1, 2), np.int32))).to(dev)
-            d_z = torch.as_tensor(np.concatenate(zs) if offs[-1] else np.zeros(1)).to(dev)
+            if philox:
+                # device draws of ONE iteration (a host-side transformer sits between the draws and the simulation)
+                d_win, d_blk1 = b_win[:n * 4].view(n, 4), b_blk[:n * 4].view(n, 4)
+                d_off, d_cnt, d_us1 = b_off[:n], b_cnt[:n], b_us[:n]
+                with torch.cuda.device(dev):
+                    if pcg64:
+                        eng._check(lib.gsm_sgs_draw_pcg64(h, _ptr(d_gen), 1, _ptr(d_region), _ptr(d_isdata),
+                                                          int(chain.block_min_x), int(chain.block_max_x), int(chain.block_min_y), int(chain.block_max_y),
+                                                          max_cells, _ptr(d_win), _ptr(d_blk1), _ptr(d_off), _ptr(d_cnt), _ptr(d_cells), _ptr(d_z),
+                                                          _ptr(d_us1), eng._stream()))
+                    else:
+                        eng._check(lib.gsm_sgs_draw_philox(h, _ptr(d_seeds), int(philox_iter0) + it, 1, _ptr(d_region), _ptr(d_isdata),
+                                                           int(chain.block_min_x), int(chain.block_max_x), int(chain.block_min_y), int(chain.block_max_y),
+                                                           max_cells, _ptr(d_win), _ptr(d_blk1), _ptr(d_off), _ptr(d_cnt), _ptr(d_cells), _ptr(d_z),
+                                                           _ptr(d_us1), eng._stream()))
+                wins, us = d_win.cpu().numpy(), d_us1.cpu().numpy()
+                blocks_cache[:, it] = d_blk1.cpu().numpy()
+            else:
+                wins = np.empty((n, 4), np.int32); offs = np.zeros(n + 1, np.int32); us = np.empty(n)
+                cells, zs = [], []
+                for c in range(n):
+                    blk, win, inds, z, us[c] = chain._draw_iteration(rngs[c], cond_is_data)
+                    blocks_cache[c, it] = blk
+                    wins[c] = win
+                    cells.append(inds); zs.append(z)
+                    offs[c + 1] = offs[c] + inds.shape[0]
+                d_win = torch.as_tensor(wins).to(dev)
+                d_off = torch.as_tensor(offs).to(dev)
+                d_cnt = None
+                d_cells = torch.as_tensor(np.ascontiguousarray(np.concatenate(cells) if offs[-1] else np.zeros((1, 2), np.int32))).to(dev)
+                d_z = torch.as_tensor(np.concatenate(zs) if offs[-1] else np.zeros(1)).to(dev)
             if dev_qt:
                 qt(cur, nxt, 0)
             elif host_nst is not None:
                 # the caller's transformer on the whole map, where the reference calls it (MCMC.py:1766)
                 nxt.copy_(f64(np.stack([nst.transform(bed_c[c].reshape(-1, 1)).reshape(H, W) for c in range(n)])))
             with torch.cuda.device(dev):
-                eng._check(lib.gsm_sgs_blocks(h, _ptr(nxt), _ptr(d_zcond), _ptr(d_win), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), lag_mi, lag_mj, hw,
-                                              rad, npts, float(vario["sill"]), _ptr(d_off), _ptr(d_cells), _ptr(d_z), max_cells, None, None,
-                                              eng._stream()))
+                eng._check(lib.gsm_sgs_blocks_batch(h, _ptr(nxt), _ptr(d_zcond), _ptr(d_win), _ptr(d_xs), _ptr(d_ys), _ptr(d_lag), lag_mi, lag_mj, hw,
+                                                    rad, npts, float(vario["sill"]), _ptr(d_off), _ptr(d_cnt), _ptr(d_cells), _ptr(d_z), max_cells,
+                                                    eng._stream()))
+                eng._check(lib.gsm_sgs_check(h, eng._stream()))
             if dev_qt:
                 qt(nxt, prop, 1)
                 loss_next, bad = loss_of(prop)

@@ -484,3 +484,40 @@ def test_blocks_beyond_the_device_limit_are_refused():
     ch.set_random_generator(rng_seed=1)
     with pytest.raises(GsmError):
         ch.run(3, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None)
+
+
+class _WrappedTransformer:
+    """A normal-score transformer that is NOT scikit-learn's class (chain_sgs accepts any object with transform /
+    inverse_transform, MCMC.py:1766, :1777): the product then calls it on the host once per iteration."""
+
+    def __init__(self, inner):
+        self.inner = inner
+
+    def transform(self, x):
+        return self.inner.transform(x)
+
+    def inverse_transform(self, x):
+        return self.inner.inverse_transform(x)
+
+
+@pytest.mark.parametrize("mode", ["replay", "pcg64", "philox"])
+def test_transformer_of_another_class_runs_on_the_host_in_every_draw_mode(mode):
+    """The same chain with scikit-learn's QuantileTransformer (on the device: gsm_qt_transform) and with that transformer behind a
+    wrapper class (called on the host where the reference calls it, the draws still made where the mode makes them): identical
+    blocks, accept masks, counts and generator state; beds and losses to the device transform's agreement with scikit-learn."""
+    from mcmc_gpu_amd import synthetic
+    outs, states = [], []
+    for wrap in (False, True):
+        prob, ch = synthetic.sgs_template(32, transform=True, light=True)
+        if wrap:
+            ch.set_normal_transformation(_WrappedTransformer(ch.nst_trans), do_transform=True)
+        ch.set_random_generator(rng_seed=2024)
+        ch.set_rng_mode(mode)
+        outs.append(ch.run(40, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None))
+        states.append(ch.rng.bit_generator.state)
+    a, b = outs
+    assert np.array_equal(a[6], b[6], equal_nan=True) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+    assert states[0] == states[1]
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-9)
+    np.testing.assert_allclose(a[0], b[0], rtol=0, atol=1e-7)
+    assert 0.05 < a[4].mean() < 0.95
