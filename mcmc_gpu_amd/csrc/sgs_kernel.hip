@@ -294,21 +294,28 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
       __syncthreads();
     }
     // selection: per sector the k8 nearest in ascending (distance, cell); sectors concatenated in angle order
-    for (int s = 0; s < 8; ++s) {
-      const int len = L.len[s];
-      if (len == 0) continue;
-      for (int e = lane; e < len; e += 64) {
-        const double d = L.list_d[s][e];
-        const int gg = L.list_g[s][e];
+    // all eight sectors at once, eight lanes each (a sector's list rarely holds more than a few dozen candidates: one sector after
+    // the other left most lanes idle): lane = 8 * sector + e mod 8 ranks its candidates against the whole list of its sector
+    {
+      const int my_s = lane >> 3;
+      int tot = 0, my_base = 0, my_len = 0;
+      for (int s = 0; s < 8; ++s) {
+        const int len = L.len[s];
+        if (s == my_s) { my_base = tot; my_len = len; }
+        tot += min(len, k8);
+      }
+      for (int e = lane & 7; e < my_len; e += 8) {
+        const double d = L.list_d[my_s][e];
+        const int gg = L.list_g[my_s][e];
         int r = 0;
-        for (int q = 0; q < len; ++q) {
-          const double dq = L.list_d[s][q];
-          const int gq = L.list_g[s][q];
+        for (int q = 0; q < my_len; ++q) {
+          const double dq = L.list_d[my_s][q];
+          const int gq = L.list_g[my_s][q];
           r += (dq < d || (dq == d && gq < gg)) ? 1 : 0;
         }
-        if (r < k8) L.nb_g[n + r] = gg;
+        if (r < k8) L.nb_g[my_base + r] = gg;
       }
-      n += min(len, k8);
+      n = tot;
     }
     __syncthreads();
     if (n > 0) break;
