@@ -239,6 +239,7 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
       const int R_lo = R + 1, R_hi = (R == 0) ? min(3, r_max) : R + 1;
       int cells_in_pass, side_w = 0;
       if (R == 0) { side_w = 2 * R_hi + 1; cells_in_pass = side_w * side_w; } else cells_in_pass = 8 * R_hi;
+      const float inv_side = 1.0f / (float)(2 * R_hi);
       for (int t0 = 0; t0 < cells_in_pass; t0 += 64) {
         const int t = t0 + lane;
         int di = 0, dj = 0;
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
           di = t / side_w - R_hi; dj = t % side_w - R_hi;
           ok = ok && !(di == 0 && dj == 0);
         } else {
-          const int side = t / (2 * R_hi), o = t - side * 2 * R_hi;
+          // t / (2 R_hi) without an integer division: (t + 1/2) / (2 R_hi) is at least 1 / (4 R_hi) away from an integer, fp32 is exact enough
+          const int side = (int)(((float)t + 0.5f) * inv_side), o = t - side * 2 * R_hi;
           if (side == 0) { di = -R_hi; dj = -R_hi + o; }
           else if (side == 1) { dj = R_hi; di = -R_hi + o; }
           else if (side == 2) { di = R_hi; dj = R_hi - o; }
@@ -340,17 +342,35 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
   const int my_rc = (lane < n) ? L.nb_rc[lane] : 0;
   const int my_i = my_rc >> 16, my_j = my_rc & 0xFFFF;
   bool lag_ok = true;
+  if (mi >= H - 1 && mj >= W - 1) {
+    // the table spans every lag of the grid (lag_extents: grids up to 2048 x 2048 lags): no range test, and the index of the pair
+    // (this lane's neighbour, neighbour j) is one subtraction -- (my_i + mi) lag_w + my_j + mj minus neighbour j's i lag_w + j
+    const int my_base = (my_i + mi) * lag_w + my_j + mj;
+    __syncthreads();
+    if (lane < n) L.nb_rc[lane] = my_i * lag_w + my_j;           // the (row, col) pairs are in registers by now
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 48; ++j) {
-    double v = 0.0;
-    if (j < n) {                                                 // wave-uniform
-      if (lane < n) {
-        const int rc = L.nb_rc[j];
-        const int di = my_i - (rc >> 16), dj = my_j - (rc & 0xFFFF);
-        if (abs(di) > mi || abs(dj) > mj) lag_ok = false; else v = lag[(di + mi) * lag_w + dj + mj];
-      } else if (lane == 48 && lagr) v = 1.0;
+    for (int j = 0; j < 48; ++j) {
+      double v = 0.0;
+      if (j < n) {                                               // wave-uniform
+        if (lane < n) v = lag[my_base - L.nb_rc[j]];
+        else if (lane == 48 && lagr) v = 1.0;
+      }
+      r[j] = v;
     }
-    r[j] = v;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 48; ++j) {
+      double v = 0.0;
+      if (j < n) {                                               // wave-uniform
+        if (lane < n) {
+          const int rc = L.nb_rc[j];
+          const int di = my_i - (rc >> 16), dj = my_j - (rc & 0xFFFF);
+          if (abs(di) > mi || abs(dj) > mj) lag_ok = false; else v = lag[(di + mi) * lag_w + dj + mj];
+        } else if (lane == 48 && lagr) v = 1.0;
+      }
+      r[j] = v;
+    }
   }
   {
     double v48 = 0.0, v49 = 0.0;
