@@ -79,16 +79,15 @@ __device__ __forceinline__ void wave_sum2_f64(double& a, double& b) {
 
 // sector b + 4 in 0..7 of atan2(dy, dx) in (b pi/4, (b+1) pi/4]
 __device__ __forceinline__ int octant(double dy, double dx) {
-  if (dy == 0.0) return (dx < 0.0) ? 7 : 3;                    // angle pi -> b = 3; angle 0 -> b = -1
+  // the same case analysis as selects (no divergent branches in the search pass):
+  //   dy == 0: angle pi -> b = 3 (sector 7), angle 0 -> b = -1 (sector 3)
+  //   dy > 0:  dx > 0: (0, pi/4] 4 | (pi/4, pi/2) 5;   dx == 0: 5;   dx < 0: (pi/2, 3pi/4] 6 | (3pi/4, pi) 7
+  //   dy < 0:  dx > 0: (-pi/4, 0) 3 | (-pi/2, -pi/4] 2;  dx == 0: 1 (-pi/2 -> (-3pi/4, -pi/2]);  dx < 0: (-3pi/4, -pi/2) 1 | (-pi, -3pi/4] 0
   const double ay = fabs(dy), ax = fabs(dx);
-  if (dy > 0.0) {
-    if (dx > 0.0) return (ay <= ax) ? 4 : 5;                   // (0, pi/4] | (pi/4, pi/2)
-    if (dx == 0.0) return 5;                                   // pi/2
-    return (ay >= ax) ? 6 : 7;                                 // (pi/2, 3pi/4] | (3pi/4, pi)
-  }
-  if (dx > 0.0) return (ay < ax) ? 3 : 2;                      // (-pi/4, 0) | (-pi/2, -pi/4]
-  if (dx == 0.0) return 1;                                     // -pi/2 -> (-3pi/4, -pi/2]
-  return (ay > ax) ? 1 : 0;                                    // (-3pi/4, -pi/2) | (-pi, -3pi/4]
+  const bool right = dx > 0.0, xz = dx == 0.0;
+  const int s_up = right ? ((ay <= ax) ? 4 : 5) : (xz ? 5 : ((ay >= ax) ? 6 : 7));
+  const int s_dn = right ? ((ay < ax) ? 3 : 2) : (xz ? 1 : ((ay > ax) ? 1 : 0));
+  return (dy == 0.0) ? ((dx < 0.0) ? 7 : 3) : ((dy > 0.0) ? s_up : s_dn);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -240,6 +239,7 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
       int cells_in_pass, side_w = 0;
       if (R == 0) { side_w = 2 * R_hi + 1; cells_in_pass = side_w * side_w; } else cells_in_pass = 8 * R_hi;
       const float inv_side = 1.0f / (float)(2 * R_hi);
+      bool long_list = false;
       for (int t0 = 0; t0 < cells_in_pass; t0 += 64) {
         const int t = t0 + lane;
         int di = 0, dj = 0;
@@ -272,6 +272,7 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
               const int s = octant(ddy, ddx);
               if (!((done_mask >> s) & 1u)) {
                 const int pos = atomicAdd(&L.len[s], 1);
+                long_list |= pos + 1 > kSgsListCap - 64;
                 L.list_d[s][pos] = d; L.list_g[s][pos] = i * W + j;
                 const double qf = d * inv_cert;
                 if (qf < (double)kSgsCertMax) atomicAdd(&L.cert[s][(int)qf], 1);
@@ -280,9 +281,13 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
           }
         }
         __syncthreads();
-        // a list that could not take another full pass is cut back to the k8 nearest (nothing beyond them can be selected)
-        for (int s = 0; s < 8; ++s)
-          if (L.len[s] > kSgsListCap - 64) sgs_prune_sector(L, s, k8, lane);
+        // a list that could not take another full pass is cut back to the k8 nearest (nothing beyond them can be selected); the lane
+        // whose insertion took a list over that mark knows: the eight lengths are only looked at then
+        if (__ballot(long_list)) {
+          for (int s = 0; s < 8; ++s)
+            if (L.len[s] > kSgsListCap - 64) sgs_prune_sector(L, s, k8, lane);
+          long_list = false;
+        }
       }
       R = R_hi;
       bool fin = false;
