@@ -250,35 +250,28 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
         } else {
           // t / (2 R_hi) without an integer division: (t + 1/2) / (2 R_hi) is at least 1 / (4 R_hi) away from an integer, fp32 is exact enough
           const int side = (int)(((float)t + 0.5f) * inv_side), o = t - side * 2 * R_hi;
-          if (side == 0) { di = -R_hi; dj = -R_hi + o; }
-          else if (side == 1) { dj = R_hi; di = -R_hi + o; }
-          else if (side == 2) { di = R_hi; dj = R_hi - o; }
-          else { dj = -R_hi; di = R_hi - o; }
+          const int e = o - R_hi;                                // position along the side, as selects: no divergent branches in the pass
+          di = (side == 0) ? -R_hi : (side == 2) ? R_hi : (side == 1) ? e : -e;
+          dj = (side == 1) ? R_hi : (side == 3) ? -R_hi : (side == 0) ? e : -e;
         }
         const int i = i0 + di, j = j0 + dj;
         ok = ok && i >= ilo && i <= ihi && j >= jlo && j <= jhi;
-        if (ok) {
-          bool has;
-          if (i >= r0 && i < r1 && j >= c0 && j < c1) {
-            const int rk = rank[(i - r0) * ww + (j - c0)];
-            has = rk < slot;                                     // -1: conditioning data; < slot: simulated before this cell
-          } else {
-            has = !isnan(g[i * W + j]);
-          }
-          if (has) {
-            const double ddx = x0 - a.xs[j], ddy = y0 - a.ys[i];
-            const double d = sqrt(ddx * ddx + ddy * ddy);
-            if (d < radius) {
-              const int s = octant(ddy, ddx);
-              if (!((done_mask >> s) & 1u)) {
-                const int pos = atomicAdd(&L.len[s], 1);
-                long_list |= pos + 1 > kSgsListCap - 64;
-                L.list_d[s][pos] = d; L.list_g[s][pos] = i * W + j;
-                const double qf = d * inv_cert;
-                if (qf < (double)kSgsCertMax) atomicAdd(&L.cert[s][(int)qf], 1);
-              }
-            }
-          }
+        // everything is computed for every lane at clamped (always valid) indices; ONE predicate guards the insertion
+        const int ic = min(max(i, ilo), ihi), jc = min(max(j, jlo), jhi);
+        const bool inwin = ic >= r0 && ic < r1 && jc >= c0 && jc < c1;
+        const int rk = rank[inwin ? (ic - r0) * ww + (jc - c0) : 0];
+        const double gv = g[ic * W + jc];
+        const double ddx = x0 - a.xs[jc], ddy = y0 - a.ys[ic];
+        const double d = sqrt(ddx * ddx + ddy * ddy);
+        const int s = octant(ddy, ddx);
+        // rk: -1 = conditioning data, < slot = simulated before this cell
+        const bool ins = ok && (inwin ? rk < slot : !isnan(gv)) && d < radius && !((done_mask >> s) & 1u);
+        if (ins) {
+          const int pos = atomicAdd(&L.len[s], 1);
+          long_list |= pos + 1 > kSgsListCap - 64;
+          L.list_d[s][pos] = d; L.list_g[s][pos] = i * W + j;
+          const double qf = d * inv_cert;
+          if (qf < (double)kSgsCertMax) atomicAdd(&L.cert[s][(int)qf], 1);
         }
         __syncthreads();
         // a list that could not take another full pass is cut back to the k8 nearest (nothing beyond them can be selected); the lane
