@@ -476,7 +476,9 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
         if philox and n_iter > 0:
             # device draws refill the SAME buffers batch after batch: the launch sequence of a full batch is a hipGraph
             # (captured on a side stream -- the legacy default stream cannot be captured)
-            use_graph = batch > 1 and os.environ.get('GSM_SGS_GRAPH', '1') != '0'
+            # GSM_SGS_GRAPH=1.  Off by default: measured, the replay of a captured batch is no faster than its launches (the queue never runs
+            # dry), and capturing + instantiating the 256 nodes of a batch costs about 35 ms -- a third of a 100-iteration run of 256 chains
+            use_graph = batch > 1 and os.environ.get('GSM_SGS_GRAPH', '0') != '0'
             i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
             kmax = min(batch, n_iter)
             b_win, b_blk, b_off, b_cnt = i32(kmax * n * 4), i32(kmax * n * 4), i32(kmax * n), i32(kmax * n)
