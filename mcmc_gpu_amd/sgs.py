@@ -452,7 +452,7 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
 
         def make_batch(d_win, d_off, off_stride, d_cnt, d_cells, d_z, d_us, d_lrec, d_arec, cell_base=None, use_graph=False):
             """gsm_sgs_batch (include/gsm.h) of one batch of iterations: the loop body of chain_sgs.run (MCMC.py:1741-1822) is issued
-            by ONE gsm_sgs_iterate call -- and, with static buffers, replayed as one hipGraph launch."""
+            by ONE gsm_sgs_iterate call -- and, with static buffers and use_graph, replayed as one hipGraph launch."""
             b = SgsBatch()
             pv = lambda t: t.data_ptr() if t is not None else None
             b.cur, b.next, b.proposed = pv(cur), pv(nxt), pv(prop) if dev_qt else None
@@ -474,7 +474,7 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
 
         it_done = 0
         if philox and n_iter > 0:
-            # device draws refill the SAME buffers batch after batch: the launch sequence of a full batch is a hipGraph
+            # device draws refill the SAME buffers batch after batch: the launch sequence of a full batch CAN be a hipGraph
             # (captured on a side stream -- the legacy default stream cannot be captured)
             # GSM_SGS_GRAPH=1.  Off by default: measured, the replay of a captured batch is no faster than its launches (the queue never runs
             # dry), and capturing + instantiating the 256 nodes of a batch costs about 35 ms -- a third of a 100-iteration run of 256 chains
