@@ -46,12 +46,18 @@
 #include "normal_score.h"
 #include "proposal_device.h"
 #include <math.h>
+#ifndef GSM_SGS_LISTCAP
+#define GSM_SGS_LISTCAP 112
+#endif
 
 namespace gsm {
 
 constexpr int kSgsMaxPts = 48;
 constexpr int kSgsMaxWin = 1024;
-constexpr int kSgsListCap = 128;          // candidates kept per sector between prunings (a scan pass appends at most 64)
+// candidates kept per sector between prunings (a scan pass appends at most 64; a list is pruned to its k8 nearest when it holds more than
+// kSgsListCap - 64).  The search structure's LDS bounds the kernel's occupancy: 128 -> 112 entries and 16-bit certification counters took
+// it from 17 KiB to 13.8 KiB per workgroup, 9 -> 11 wavefronts per CU: +9 % per iteration at 256 chains (96 entries: more pruning, no more)
+constexpr int kSgsListCap = GSM_SGS_LISTCAP;
 constexpr int kSgsCertMax = 128;          // rings with certification counters; beyond, a sector completes by exhaustion only
 constexpr uint64_t kSgsPendingTag = 0x7FF8C0DE00000000ull;   // neighbour record: NaN-boxed block-local index of a cell visited earlier
 
@@ -125,7 +131,8 @@ struct SgsSearchLds {
   int32_t list_g[8][kSgsListCap];
   int32_t len[8];
   int32_t cum[8];
-  int32_t cert[8][kSgsCertMax];           // candidates of a sector by certification ring
+  uint32_t cert[8][kSgsCertMax / 2];      // candidates of a sector by certification ring: 16-bit counters, two per word (a ring holds
+                                          // at most 8 x 127 cells).  The kernel's occupancy is bounded by this structure's size.
   int32_t nb_g[kSgsMaxPts];
   int32_t nb_rc[kSgsMaxPts];            // (row << 16) | col
   double tmp_d[kSgsMaxPts];
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
     // sector s: extent (in cells) along its primary axis on its side.  dy = y0 - y > 0 <=> rows with smaller y.
     const int e_ypos = (sy > 0.0) ? e_up : e_dn, e_yneg = (sy > 0.0) ? e_dn : e_up;
     const int e_xpos = (sx > 0.0) ? e_lf : e_rt, e_xneg = (sx > 0.0) ? e_rt : e_lf;
-    for (int q = lane; q < 8 * kSgsCertMax; q += 64) (&L.cert[0][0])[q] = 0;
+    for (int q = lane; q < 8 * kSgsCertMax / 2; q += 64) (&L.cert[0][0])[q] = 0u;
     if (lane < 8) { L.len[lane] = 0; L.cum[lane] = 0; }
     __syncthreads();
     int my_ext = 0;
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
           long_list |= pos + 1 > kSgsListCap - 64;
           L.list_d[s][pos] = d; L.list_g[s][pos] = i * W + j;
           const double qf = d * inv_cert;
-          if (qf < (double)kSgsCertMax) atomicAdd(&L.cert[s][(int)qf], 1);
+          if (qf < (double)kSgsCertMax) { const int qi = (int)qf; atomicAdd(&L.cert[s][qi >> 1], 1u << (16 * (qi & 1))); }
         }
         __syncthreads();
         // a list that could not take another full pass is cut back to the k8 nearest (nothing beyond them can be selected); the lane
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
       bool fin = false;
       if (lane < 8) {
         int c = L.cum[lane];
-        for (int q = R_lo; q <= R && q < kSgsCertMax; ++q) c += L.cert[lane][q];
+        for (int q = R_lo; q <= R && q < kSgsCertMax; ++q) c += (int)((L.cert[lane][q >> 1] >> (16 * (q & 1))) & 0xFFFFu);
         L.cum[lane] = c;
         fin = c >= k8 || (double)my_ext <= floor((double)R * my_fac + 1e-6);
       }
