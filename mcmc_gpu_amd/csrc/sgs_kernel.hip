@@ -47,7 +47,7 @@
 #include "proposal_device.h"
 #include <math.h>
 #ifndef GSM_SGS_LISTCAP
-#define GSM_SGS_LISTCAP 112
+#define GSM_SGS_LISTCAP 80
 #endif
 
 namespace gsm {
@@ -55,10 +55,12 @@ namespace gsm {
 constexpr int kSgsMaxPts = 48;
 constexpr int kSgsMaxWin = 1024;
 // candidates kept per sector between prunings (a scan pass appends at most 64; a list is pruned to its k8 nearest when it holds more than
-// kSgsListCap - 64).  The search structure's LDS bounds the kernel's occupancy: 128 -> 112 entries and 16-bit certification counters took
-// it from 17 KiB to 13.8 KiB per workgroup, 9 -> 11 wavefronts per CU: +9 % per iteration at 256 chains (96 entries: more pruning, no more)
+// kSgsListCap - 64 = 16).  The search structure's LDS bounds the kernel's occupancy: 128 -> 80 entries, 64 rings of 16-bit certification
+// counters instead of 128 of 32 bits took it from 17 KiB to 9.7 KiB per workgroup = 9 -> 16 wavefronts per CU (the register budget's
+// four per SIMD): +14 % per iteration at 256 chains, the extra prunings included (same-box A/B of 128 / 112 / 96 / 88 / 80 entries)
 constexpr int kSgsListCap = GSM_SGS_LISTCAP;
-constexpr int kSgsCertMax = 128;          // rings with certification counters; beyond, a sector completes by exhaustion only
+constexpr int kSgsCertMax = 64;           // rings with certification counters (the driver's 30 km at 500 m = 60 rings); beyond, a sector
+                                          // completes by exhaustion only
 constexpr uint64_t kSgsPendingTag = 0x7FF8C0DE00000000ull;   // neighbour record: NaN-boxed block-local index of a cell visited earlier
 
 __device__ __forceinline__ double wave_sum_f64(double v) { return dev::wave64_sum(v); }     // DPP tree, wave-uniform result
