@@ -204,6 +204,13 @@ int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int32_t batch, 
 int gsm_set_fused(gsm_handle h, int32_t on);
 /* Which form the last gsm_run_philox call on this handle ran: 1 = fused chain kernel, 0 = the two-kernel pipeline. */
 int gsm_last_run_fused(gsm_handle h);
+/* Which step kernels this handle's static fields and block table select (decided once per table, for gsm_run_replay and
+ * gsm_run_philox alike, so that fused == propose + replay holds bit for bit): 1 = the strip kernels (chain_strip_kernel.hip:
+ * 512-thread workgroups, two chains per CU, candidate bed in a (bh + 2) x (bw + 2) LDS tile), 0 = the flux-tile kernels
+ * (1024-thread workgroups, one chain per CU; block tables whose strips would exceed 16 rows or whose proposal work area
+ * exceeds 80 KiB; GSM_STRIP=0).  Needs gsm_set_static and gsm_set_blocks.  Same arithmetic per cell (MCMC.py:1279-1360,
+ * Topography.py:592-600); the window sums of a step are taken in another order (loss within 1e-15 relative). */
+int gsm_strip_active(gsm_handle h);
 
 /* Average duration in milliseconds of the step kernel / the proposal kernel over the launches made
  * by the last gsm_run_philox call, measured with HIP events on the streams the kernels ran on

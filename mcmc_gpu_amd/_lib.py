@@ -16,7 +16,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libgsm_hip.so"
 HEADER = PKG_DIR.parent / "include" / "gsm.h"
-SOURCES = ["gsm_api.hip", "gsm_version.hip", "step_kernel.hip", "step_flux_kernel.hip", "chain_fused_kernel.hip", "proposal_kernel.hip", "cholesky_kernel.hip", "sgs_kernel.hip", "pcg64_kernel.hip"]
+SOURCES = ["gsm_api.hip", "gsm_version.hip", "step_kernel.hip", "step_flux_kernel.hip", "chain_fused_kernel.hip", "chain_strip_kernel.hip", "proposal_kernel.hip", "cholesky_kernel.hip", "sgs_kernel.hip", "pcg64_kernel.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-Wno-unused-value", "-Wno-unused-result"]
 # per-file extras.  step_flux_kernel: without machine LICM the fp64 polynomial constants of exp() are materialised at
@@ -26,6 +26,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 # a pipeline drain per step: 12.0 -> 9.x ms per 32768 proposals, scripts/kbench.py).
 EXTRA_FLAGS = {"step_flux_kernel.hip": ["-mllvm", "-disable-machine-licm"],
                "chain_fused_kernel.hip": ["-mllvm", "-disable-machine-licm"],
+               "chain_strip_kernel.hip": ["-mllvm", "-disable-machine-licm"],
                "cholesky_kernel.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 OBJ_DIR = PKG_DIR / "_build"
 
@@ -199,6 +200,7 @@ def load() -> C.CDLL:
     lib.gsm_enable_timing.argtypes = [vp, i32]
     lib.gsm_set_fused.argtypes = [vp, i32]
     lib.gsm_last_run_fused.argtypes = [vp]
+    lib.gsm_strip_active.argtypes = [vp]
     lib.gsm_last_timing.argtypes = [vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(dbl), C.POINTER(i32)]
     lib.gsm_cov_assemble.argtypes = [vp, i32, i32, dbl, C.POINTER(Vario), vp, vp, i64, vp]
     lib.gsm_cholesky_upper.argtypes = [vp, vp, i32, i64, dbl, vp]

@@ -539,6 +539,7 @@ static hipError_t launch_fused_t(const FusedArgs& a, hipStream_t st) {
 }
 
 bool fused_supported(const FusedArgs& a) {
+  if (a.T.strip && a.P.tab_max > 0) return true;
   return step_flux_supported(a.T) && a.P.tab_max > 0 && fused_lds_doubles(a) * sizeof(double) <= 160 * 1024 &&
          2 * a.P.tiles1_max <= kNW * kUPW && a.P.tiles2_max <= 16;
 }
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(kRsThreads) void resampled_from_records_kernel(cons
   }
 }
 
-static hipError_t launch_resampled_from_records(const FusedArgs& a, hipStream_t st) {
+hipError_t launch_resampled_from_records(const FusedArgs& a, hipStream_t st) {
   const int W = a.T.S.W, H = a.T.S.H;
   const int wt = std::min(W, kRsColTile);
   // ~32 KiB of LDS per workgroup: several workgroups per CU hide each other's memory latency
@@ -630,6 +631,11 @@ static hipError_t launch_resampled_from_records(const FusedArgs& a, hipStream_t 
 // One launch: propose_scalars_kernel for all steps must have filled a.P.scalars (n_chains x a.P.n_steps records).
 hipError_t launch_chain_fused(const FusedArgs& a_in, hipStream_t st) {
   if (!fused_supported(a_in)) return hipErrorInvalidValue;
+  if (a_in.T.strip) {                               // two chains per CU: chain_strip_kernel.hip
+    const hipError_t es = launch_chain_strip(a_in, st);
+    if (es != hipSuccess) return es;
+    return launch_resampled_from_records(a_in, st);
+  }
   FusedArgs a = a_in;
   { static int dbg = -1; if (dbg < 0) { const char* v = getenv("GSM_PROPOSE_DBG"); dbg = v ? atoi(v) : 0; } a.P.dbg = dbg; }   // diagnostics only
   a.work_len = fused_work_len(a);

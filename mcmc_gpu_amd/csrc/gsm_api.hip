@@ -366,6 +366,18 @@ extern "C" int gsm_residual(gsm_handle h, const double* beds, double* residual, 
   return GSM_OK;
 }
 
+// 1 when this handle's static fields and block table go to the strip kernels (chain_strip_kernel.hip)
+static int strip_for(gsm_handle h) {
+  return (h->have_static && h->have_blocks &&
+          strip_table_ok(h->S, h->B, std::max(4 * h->lds_x_half, h->lds_tt), h->prop_tiles1, h->prop_tiles)) ? 1 : 0;
+}
+
+extern "C" int gsm_strip_active(gsm_handle h) {
+  if (!h) return GSM_E_ARG;
+  if (!h->have_static || !h->have_blocks) return fail(h, GSM_E_STATE, "gsm_strip_active: call gsm_set_static and gsm_set_blocks first");
+  return strip_for(h);
+}
+
 static int check_device_flag(gsm_handle h, hipStream_t st, const char* who) {
   int32_t flag = 0;
   HIPCHK(h, hipMemcpyAsync(&flag, h->d_err, sizeof(flag), hipMemcpyDeviceToHost, st));
@@ -394,7 +406,7 @@ extern "C" int gsm_run_replay(gsm_handle h, int32_t n_steps, void* beds, void* e
   HIPCHK(h, hipSetDevice(h->device));
   StepArgs a{};
   a.S = h->S; a.B = h->B;
-  a.n_chains = h->n_chains; a.n_steps = n_steps; a.tile_cap = h->tile_cap;
+  a.n_chains = h->n_chains; a.n_steps = n_steps; a.tile_cap = h->tile_cap; a.strip = strip_for(h);
   a.beds = beds; a.energy = energy; a.f32_state = h->f32_state; a.resampled = resampled; a.loss_sum = loss_sum;
   a.size_idx = size_idx; a.centre = centre; a.u = u; a.fields = fields; a.field_stride = field_stride;
   a.loss = loss; a.accept = accept; a.blocks = nullptr;
@@ -590,7 +602,7 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
     FusedArgs fa{};
     StepArgs& a = fa.T;
     a.S = h->S; a.B = h->B;
-    a.n_chains = h->n_chains; a.n_steps = seg_max; a.tile_cap = h->tile_cap;
+    a.n_chains = h->n_chains; a.n_steps = seg_max; a.tile_cap = h->tile_cap; a.strip = strip_for(h);
     a.beds = beds; a.energy = energy; a.f32_state = h->f32_state; a.resampled = resampled; a.loss_sum = loss_sum;
     a.loss = loss; a.accept = accept; a.blocks = blocks;
     a.rec_stride = n_steps; a.rec_offset = 0; a.in_stride = seg_max;
@@ -692,7 +704,7 @@ extern "C" int gsm_run_philox(gsm_handle h, int32_t n_steps, int64_t step0, int3
     HIPCHK(h, hipStreamWaitEvent(st, h->ev_prop[k & 1], 0));
     StepArgs a{};
     a.S = h->S; a.B = h->B;
-    a.n_chains = h->n_chains; a.n_steps = nb; a.tile_cap = h->tile_cap;
+    a.n_chains = h->n_chains; a.n_steps = nb; a.tile_cap = h->tile_cap; a.strip = strip_for(h);
     a.beds = beds; a.energy = energy; a.f32_state = h->f32_state; a.resampled = resampled; a.loss_sum = loss_sum;
     a.size_idx = s.size_idx; a.centre = s.centre; a.u = s.u; a.fields = s.fields; a.field_stride = h->field_stride;
     a.loss = loss; a.accept = accept; a.blocks = blocks;

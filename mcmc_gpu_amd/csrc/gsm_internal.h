@@ -75,6 +75,8 @@ struct StepArgs {
   int64_t rec_offset;     // first record of this launch within a chain's row
   int64_t in_stride;      // records per chain in the proposal arrays (size_idx, centre, u, fields)
   int32_t* err_flag;      // device int, set non-zero on bad device data
+  int strip;              // 1: the strip kernels (chain_strip_kernel.hip) take this block table; decided once per table by
+                          // strip_table_ok so that the fused kernel and the replay kernel of a handle always pair up
 };
 
 // per-proposal scalars written by propose_scalars_kernel and read (uniformly) by propose_kernel
@@ -252,6 +254,10 @@ hipError_t launch_k2_tables(const BlockTable& B, const int32_t* k2_off, double r
 hipError_t launch_spectral_from_noise(const ProposeArgs& a, const int32_t* size_idx, const double* rf_scalars, const double* noise_re,
                                       const double* noise_im, const double* nugget_field, hipStream_t st);
 hipError_t launch_chain_fused(const FusedArgs& a, hipStream_t st);
+hipError_t launch_chain_strip(const FusedArgs& a, hipStream_t st);
+hipError_t launch_step_strip(const StepArgs& a, hipStream_t st);
+hipError_t launch_resampled_from_records(const FusedArgs& a, hipStream_t st);
+bool strip_table_ok(const StaticFields& S, const BlockTable& B, int lds_main, int tiles1_max, int tiles2_max);
 bool fused_supported(const FusedArgs& a);
 int propose_max_tiles_per_wave();
 int propose_max_tiles1_per_wave();

@@ -336,6 +336,7 @@ static hipError_t launch_step_t(const StepArgs& a, hipStream_t st) {
 hipError_t launch_step(const StepArgs& a, hipStream_t st) {
   // window cells per thread: the largest block of the table decides the instantiation
   // (window cells <= KMAX * NT and tile cells <= (KMAX + 1) * NT)
+  if (a.strip) return launch_step_strip(a, st);      // pairs with chain_strip_kernel (same sums)
   const int max_win = std::max(a.B.max_bh * a.B.max_bw, a.tile_cap - 1024);
   static int variant = -1;
   if (variant < 0) { const char* v = getenv("GSM_STEP_VARIANT"); variant = v ? atoi(v) : 3; }

@@ -348,6 +348,13 @@ class GsmEngine:
     def last_run_fused(self) -> int:
         return int(self.lib.gsm_last_run_fused(self.h))
 
+    def strip_active(self) -> bool:
+        """True when this handle's tables go to the strip kernels (two chains per CU), False for the flux-tile kernels."""
+        rc = int(self.lib.gsm_strip_active(self.h))
+        if rc < 0:
+            self._check(rc)
+        return bool(rc)
+
     def run_philox(self, n_steps, step0, seeds, rf, batch=8, out=None, to_host=True):
         """n_steps Metropolis steps for every chain with on-device proposals.
         Returns (loss, accept, blocks): (n_chains, n_steps), (n_chains, n_steps), (n_chains, n_steps, 4)."""

@@ -1,0 +1,62 @@
+"""-m gpu: the strip kernels (chain_strip_kernel.hip: 512-thread workgroups, two chains per CU) against the flux-tile kernels
+(chain_fused_kernel / step_flux_kernel, GSM_STRIP=0) on the same proposals.  Per-cell arithmetic is the same, operation for
+operation (reference gstatsMCMC/MCMC.py:1279-1360, Topography.py:592-600): beds, energies, accept masks, blocks and resampled
+counts must be identical; the loss differs by the order of the window sums only (tolerance 1e-12 relative, stated here)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import mcmc_oracle as orc
+from gpu_common import make_engine
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + '/oracle'); sys.path.insert(0, {root!r} + '/tests')
+import mcmc_oracle as orc
+from gpu_common import make_engine
+H, n, state = {H}, {n}, {state!r}
+eng, prob, cfg, pairs, masks, rfp = make_engine(H, 3, state_dtype=state)
+rfp = orc.standard_rf_params(); rfp.resolution = prob["resolution"]
+eng.set_centres(np.ones_like(cfg.region_mask))
+beds0 = np.stack([orc.chain_initial_bed(prob, c) for c in range(3)])
+eng.set_state(beds0)
+loss, acc, blk = eng.run_philox(n, 5, [11, 12, 13], rfp, batch=n)
+np.savez({out!r}, strip=int(eng.strip_active()), loss=loss, acc=acc, blk=blk, beds=eng.beds.cpu().numpy(),
+         energy=eng.energy.cpu().numpy(), res=eng.resampled.cpu().numpy())
+"""
+
+
+def _run_child(tmp_path, H, n, state, strip):
+    out = str(tmp_path / f"r_{H}_{state}_{strip}.npz")
+    env = dict(os.environ, GSM_STRIP=str(strip))
+    r = subprocess.run([sys.executable, "-c", _CHILD.format(root=str(ROOT), H=H, n=n, state=state, out=out)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return np.load(out)
+
+
+@pytest.mark.parametrize("H,n,state", [(64, 80, "f64"), (256, 60, "f64"), (64, 40, "f32")])
+def test_strip_kernels_equal_flux_tile_kernels(tmp_path, H, n, state):
+    """GSM_STRIP is read once per process: one child per setting.  256: blocks 50-80 (16-, 32- and 64-lane strips, windows
+    clipped on every side of the grid since centres may lie anywhere)."""
+    a = _run_child(tmp_path, H, n, state, 1)
+    b = _run_child(tmp_path, H, n, state, 0)
+    assert int(a["strip"]) == 1 and int(b["strip"]) == 0          # the paths under test really ran
+    for k in ("acc", "blk", "beds", "energy", "res"):
+        assert np.array_equal(a[k], b[k]), k
+    np.testing.assert_allclose(a["loss"], b["loss"], rtol=1e-12)
+    assert 0.2 < a["acc"].mean() < 1.0
+
+
+def test_standard_tables_run_the_strip_kernels():
+    for H in (64, 256):
+        eng, *_ = make_engine(H, 2)
+        assert eng.strip_active()
+        eng.close()
