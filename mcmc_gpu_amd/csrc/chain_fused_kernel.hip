@@ -56,7 +56,7 @@ size_t fused_lds_doubles(const FusedArgs& a) {
   return (size_t)fused_work_len(a) + (size_t)fused_fld_len(a) + 4 * kNW + 32 + 16 + kMathTabDoubles;
 }
 
-static_assert(sizeof(PropScalars) == 120, "PropScalars: 120-byte records, read field by field with scalar loads");
+static_assert(sizeof(PropScalars) == 136, "PropScalars: 136-byte records, read field by field with scalar loads");
 
 // The per-step record (propose_scalars_kernel's output) is read through the constant address space: the address is uniform
 // and the memory is never written by this kernel, so every access is a scalar load.  Each phase re-reads the few fields it

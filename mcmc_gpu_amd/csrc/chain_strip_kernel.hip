@@ -11,7 +11,7 @@
 //
 // Why two chains per CU: chain_fused_kernel (1024 threads, 159 KiB of LDS: two flux tiles or four coefficient planes plus
 // the DFT tables, one workgroup per CU) leaves 38 % of its wave-cycles waiting at barriers and on memory with nothing
-// else to run.  Here the step needs no LDS (strip_step.h), the DFT tables are read from L2, and the field tile shares the
+// else to run.  Here the step needs no LDS (strip_step.h), the DFT operands come from 1-D twiddle tables (4 KiB of LDS instead of 66), and the field tile shares the
 // proposal's work area, so a second workgroup fits and fills those waits.
 //
 // Per step of chain_strip_kernel:
@@ -44,16 +44,17 @@ constexpr int kSMAXT = 16 / kSW;  // stage-2 tiles per wave
 
 static int strip_tile_len(const BlockTable& B) { return (B.max_bh + 2) * (B.max_bw + 2); }   // candidate-bed tile: block + halo ring
 static int strip_main_len(const FusedArgs& a) { return std::max(a.P.lds_main, strip_tile_len(a.T.B)); }
-size_t fused_strip_lds_doubles(const FusedArgs& a) { return (size_t)strip_main_len(a) + 16 + 32 + 16 + kMathTabDoubles; }
+constexpr int kStripAux = 16 + 32 + 16 + kMathTabDoubles + 4 * kT1S;     // wave partials (+ the carried sums), proposal reductions, math table, 1-D twiddle tables
+size_t fused_strip_lds_doubles(const FusedArgs& a) { return (size_t)strip_main_len(a) + kStripAux; }
 
 // One decision per (static fields, block table): both strip kernels or neither (the sums of a step are taken in another
 // order than in the flux-tile kernels, and fused == propose + replay must hold bit for bit).  GSM_STRIP=0 switches them off.
 bool strip_table_ok(const StaticFields& S, const BlockTable& B, int lds_main, int tiles1_max, int tiles2_max) {
   static int on = -1;
   if (on < 0) { const char* v = getenv("GSM_STRIP"); on = v ? atoi(v) : 1; }
-  const size_t lds = ((size_t)std::max(lds_main, strip_tile_len(B)) + 16 + 32 + 16 + kMathTabDoubles) * sizeof(double);
+  const size_t lds = ((size_t)std::max(lds_main, strip_tile_len(B)) + kStripAux) * sizeof(double);
   return on && S.sA != nullptr && (uint64_t)S.H * S.W * 48u < 0x80000000ull && B.n_sizes <= 64 && strip::table_ok(B.max_bh, B.max_bw) &&
-         lds <= 80 * 1024 && 2 * tiles1_max <= kSW * kSUPW && tiles2_max <= kSW * kSMAXT;
+         B.max_bh <= kT1S && B.max_bw <= kT1S && lds <= 80 * 1024 && 2 * tiles1_max <= kSW * kSUPW && tiles2_max <= kSW * kSMAXT;
 }
 
 typedef const __attribute__((address_space(4))) PropScalars* srec_t;
@@ -87,9 +88,11 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
   typedef const __attribute__((address_space(4))) FusedArgs* cargs_t;
   auto kargs = [] { cargs_t p = (cargs_t)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p)); return p; };
   extern __shared__ double lds[];                                  // planes -> T^T -> field tile
-  double* __restrict__ red = lds + fa.work_len;                    // [16] wave partials of the step (8 used)
-  double* __restrict__ red2 = red + 16;                            // [32 + 16] proposal reductions
+  double* __restrict__ red = lds + fa.work_len;                    // [16] wave partials of the step (8 used, the rest 0)
+  double* __restrict__ red2 = red + 16;                            // [32] proposal reductions, [16] carried sums: s_hi, s_lo, loss_prev
+  double* __restrict__ carry = red2 + 32;
   double* __restrict__ mtab = red2 + 32 + 16;                      // [kMathTabDoubles] log / sincos table (math_tables.h)
+  double* __restrict__ t1 = mtab + kMathTabDoubles;                // [4][kT1S] 1-D twiddle tables of the step's block: cos, sin (height), cos, -sin (width)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -104,19 +107,26 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
   const uint32_t n_cells = (uint32_t)gH * (uint32_t)gW;
   const srec_t rec0 = (srec_t)(uintptr_t)(fa.P.scalars + (size_t)chain * fa.P.n_steps);
   const uint64_t seed = fa.P.seeds[chain];
+  const int dbg = fa.P.dbg;      // diagnostics only (GSM_PROPOSE_DBG): 128 / 256 / 512 / 1024 skip phase D / phase A / the state loads / the commit
   for (int i = tid; i < kMathTabDoubles; i += kST) mtab[i] = fa.P.mathtab[i];
   if (tid < 16) red[tid] = 0.0;
   __syncthreads();
 
-  double s_hi = fa.T.loss_sum[2 * chain], s_lo = fa.T.loss_sum[2 * chain + 1];
-  double loss_prev = (s_hi + s_lo) / two_sigma2;
+  // The carried compensated sum and the current loss are the same numbers in every thread and are needed once per step, at
+  // the accept test: they live in LDS between the tests (thread 0 writes them back after an accepted step) instead of in six
+  // vector registers of every thread through the whole step.
+  if (tid == 0) {
+    const double h0 = fa.T.loss_sum[2 * chain], l0 = fa.T.loss_sum[2 * chain + 1];
+    carry[0] = h0; carry[1] = l0; carry[2] = (h0 + l0) / two_sigma2;
+  }
+  __syncthreads();
   int pr0 = 0, pr1 = 0, pc0 = 0, pc1 = 0;      // window of the previous step if it was accepted, else empty
   const NoiseIn no_noise{nullptr, nullptr, nullptr};
   auto prop_rec = [&](srec_t r) {
     PropScalars q;
     q.scale = r->scale; q.nug = r->nug; q.aa = r->aa; q.m_const = r->m_const; q.m_kappa = r->m_kappa;
     q.bh = r->bh; q.bw = r->bw; q.fy_off = r->fy_off; q.g_off = r->g_off; q.pad = r->pad; q.mask_off = r->mask_off;
-    q.m_nc = r->m_nc; q.m_m1 = r->m_m1;
+    q.m_nc = r->m_nc; q.m_m1 = r->m_m1; q.m_bh = r->m_bh; q.m_bw = r->m_bw;
     return q;
   };
 
@@ -127,7 +137,17 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
     const srec_t rec = rec0 + s;
     const int s_row = rec->row, s_col = rec->col, s_bh = rec->bh, s_bw = rec->bw;
 
-    // ---- P: folded coefficients -> LDS planes ---------------------------------------------------------------------------
+    // ---- P: twiddle tables of this block shape and folded coefficients -> LDS ------------------------------------------------
+    {
+      const cargs_t K = kargs();
+      const double* __restrict__ g1 = K->P.tab1d;
+      if (tid < 2 * s_bh) t1[(tid < s_bh) ? tid : kT1S + tid - s_bh] = g1[rec->t1h_off + tid];
+      else if (tid >= 256 && tid < 256 + 2 * s_bw) {
+        const int i = tid - 256;
+        const double v = g1[rec->t1w_off + i];
+        t1[2 * kT1S + ((i < s_bw) ? i : kT1S + i - s_bw)] = (i < s_bw) ? v : -v;
+      }
+    }
     {
       const cargs_t K = kargs();
       const ProposeArgs pa = load_cs(&K->P);
@@ -149,14 +169,14 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
         const cargs_t K = kargs();
         const ProposeArgs pa = load_cs(&K->P);
         const PropScalars q = prop_rec(rec);
-        dft_stage1<kSW, kSUPW, false>(wave, ptid & 63, pa, q, prop_geom(pa, q.bh, q.bw), lds, nullptr, uc, us);
+        dft_stage1<kSW, kSUPW, 2>(wave, ptid & 63, pa, q, prop_geom(pa, q.bh, q.bw), lds, t1, uc, us);
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has finished reading the planes
       {
         const cargs_t K = kargs();
         const ProposeArgs pa = load_cs(&K->P);
         relaunder();
-        dft_tt_write<kSW, kSUPW>(wave, ptid & 63, prop_geom(pa, s_bh, s_bw), lds, uc, us);
+        dft_tt_write<kSW, kSUPW, true>(wave, ptid & 63, prop_geom(pa, s_bh, s_bw), lds, uc, us);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -172,7 +192,7 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
       double mreg[kSMAXT][8];
       relaunder();
       const int ln = ptid & 63;
-      dft_stage2<kSW, kSMAXT, false>(wave, ln, pa, q, pg, lds, nullptr, fe, fo);
+      dft_stage2<kSW, kSMAXT, 2>(wave, ln, pa, q, pg, lds, t1 + 2 * kT1S, fe, fo);
       mask_prefetch<kSW, kSMAXT>(wave, ln, pa, q, pg, mreg);
       double mean;
       const double gain = standardise<kSW, kSMAXT>(wave, ln, q, pg, dc0, red2, fe, fo, mean);     // contains a barrier
@@ -198,12 +218,20 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
     {
       double vb[kNR + 2], ve[kNR];
       double2 a2[strip::kNA];
-      if (G.interior) strip::load_state<TS, true>(L, cfg.n, gW, r_bed, r_en, r_st, vb, ve, a2);
+      if (dbg & 512) {
+#pragma unroll
+        for (int i = 0; i < kNR + 2; ++i) vb[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < kNR; ++i) ve[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < strip::kNA; ++i) a2[i] = make_double2(0.0, 0.0);
+      } else if (G.interior) strip::load_state<TS, true>(L, cfg.n, gW, r_bed, r_en, r_st, vb, ve, a2);
       else strip::load_state<TS, false>(L, cfg.n, gW, r_bed, r_en, r_st, vb, ve, a2);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // field tile complete; the state loads stay in flight
       const int ts = s_bw + 2;
       auto field = [&](int jj, bool in) { return in ? lds[L.tidx + jj * ts] : 0.0; };
-      if (G.interior) strip::phase_a<TS, true>(L, cfg.n, gW, s_bw, r_st, field, lds, vb, ve, a2, upd_bits, acc_old, guard);
+      if (dbg & 256) { upd_bits = 0u; acc_old = 0.0; guard = false; }
+      else if (G.interior) strip::phase_a<TS, true>(L, cfg.n, gW, s_bw, r_st, field, lds, vb, ve, a2, upd_bits, acc_old, guard);
       else strip::phase_a<TS, false>(L, cfg.n, gW, s_bw, r_st, field, lds, vb, ve, a2, upd_bits, acc_old, guard);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // candidate-bed tile complete
@@ -212,23 +240,36 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
       double acc_new;
       const cargs_t K = kargs();
       const strip::StepConsts SC{K->T.S.res, K->T.S.rcp_res, K->T.S.two_res, K->T.S.rcp_two_res};
-      if (G.interior) strip::phase_d<TS, FAST_DIV, true>(L, cfg.n, gW, s_bw, r_st, n_cells * 16u, SC, lds, en, acc_new);
+      if (dbg & 128) {
+        acc_new = 0.0;
+#pragma unroll
+        for (int i = 0; i < kNR; ++i) en[i] = 0.0;
+      } else if (G.interior) strip::phase_d<TS, FAST_DIV, true>(L, cfg.n, gW, s_bw, r_st, n_cells * 16u, SC, lds, en, acc_new);
       else strip::phase_d<TS, FAST_DIV, false>(L, cfg.n, gW, s_bw, r_st, n_cells * 16u, SC, lds, en, acc_new);
       double delta = acc_new - acc_old;
       if (guard) delta = INFINITY;
       const double w_delta = wave64_sum(delta);
       if (lane == 0) red[wave] = w_delta;
     }
-    strip::read_candidate(L, cfg.n, s_bw, lds, upd_bits, vn);
+    if (dbg & 1024) {
+#pragma unroll
+      for (int i = 0; i < kNR; ++i) vn[i] = 0.0;
+    } else strip::read_candidate(L, cfg.n, s_bw, lds, vn);
+    const double s_hi = carry[0], s_lo = carry[1];
+    double loss_prev = carry[2];
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const double sd = strip::waves_sum(red, lane);
     double c_hi, c_lo, loss_next;
     const bool acc = decide<FAST_DIV>(sd, s_hi, s_lo, two_sigma2, rcp_two_sigma2, loss_prev, rec->u, c_hi, c_lo, loss_next);
-    if (acc) {
+    if (acc && !(dbg & 1024)) {
       if (G.interior) strip::commit<TS, true, false>(L, cfg.n, gW, r_bed, r_en, r_en, vn, en, upd_bits);
       else strip::commit<TS, false, false>(L, cfg.n, gW, r_bed, r_en, r_en, vn, en, upd_bits);
-      two_sum(c_hi, c_lo, s_hi, s_lo);
       loss_prev = loss_next;
+      if (tid == 0) {
+        double n_hi, n_lo;
+        two_sum(c_hi, c_lo, n_hi, n_lo);
+        carry[0] = n_hi; carry[1] = n_lo; carry[2] = loss_next;
+      }
       pr0 = G.r0; pr1 = G.r0 + G.wh; pc0 = G.c0; pc1 = G.c0 + G.ww;
     } else {
       pr0 = pr1 = pc0 = pc1 = 0;
@@ -242,9 +283,9 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
       if (a.blocks) { a.blocks[4 * rout] = s_row; a.blocks[4 * rout + 1] = s_col; a.blocks[4 * rout + 2] = s_bh; a.blocks[4 * rout + 3] = s_bw; }
     }
   }
-  if (tid == 0) {
-    fa.T.loss_sum[2 * chain] = s_hi;
-    fa.T.loss_sum[2 * chain + 1] = s_lo;
+  if (tid == 0) {                      // thread 0 wrote the sums itself: program order, no barrier needed
+    fa.T.loss_sum[2 * chain] = carry[0];
+    fa.T.loss_sum[2 * chain + 1] = carry[1];
   }
 }
 
@@ -326,7 +367,7 @@ __global__ __launch_bounds__(kST, 4) void step_strip_kernel(const StepArgs a) {
       const double w_delta = wave64_sum(delta);
       if (lane == 0) red[wave] = w_delta;
     }
-    strip::read_candidate(L, cfg.n, bw, tile, upd_bits, vn);
+    strip::read_candidate(L, cfg.n, bw, tile, vn);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const double sd = strip::waves_sum(red, lane);
     double c_hi, c_lo, loss_next;

@@ -26,6 +26,7 @@ struct gsm_context {
   double* d_masks = nullptr;
   double* d_tables = nullptr;
   int32_t *d_fy_off = nullptr, *d_g_off = nullptr;
+  double* d_tab1d = nullptr; int32_t* d_t1_off = nullptr;   // 1-D twiddle tables of the strip kernel's DFT stages
   int lds_sx = 0, lds_st = 0, lds_x_half = 0, lds_tt = 0, prop_tiles = 0, prop_tiles1 = 0;
   int tables_len = 0, tab_max = 0;
   double* d_k2 = nullptr;        // per-size k^2 tables of the spectral amplitude (depend on rf.resolution)
@@ -127,6 +128,8 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_svx) hipFree(h->d_svx);
   if (h->d_svy) hipFree(h->d_svy);
   if (h->d_ds) hipFree(h->d_ds);
+  if (h->d_tab1d) hipFree(h->d_tab1d);
+  if (h->d_t1_off) hipFree(h->d_t1_off);
   if (h->d_sA) hipFree(h->d_sA);      // d_sB, d_sC point into the same allocation
   if (h->d_bh) hipFree(h->d_bh);
   if (h->d_bw) hipFree(h->d_bw);
@@ -325,6 +328,24 @@ extern "C" int gsm_set_blocks(gsm_handle h, int32_t n_sizes, const int32_t* bh, 
   HIPCHK(h, dup_device(&h->d_tables, tb.data(), tb.size(), st));
   HIPCHK(h, dup_device(&h->d_fy_off, fy_off.data(), fy_off.size(), st));
   HIPCHK(h, dup_device(&h->d_g_off, g_off.data(), g_off.size(), st));
+  {
+    // 1-D twiddle tables: for every distinct block length n the values cos / sin(2 pi m / n), m < n -- the numbers the 2-D
+    // tables above hold at (k, j) with m = (k * j) mod n (same expression, same libm calls: bit-identical operands)
+    std::vector<int32_t> t1_off(max_len + 1, 0);
+    std::vector<double> t1;
+    std::vector<char> seen(max_len + 1, 0);
+    for (int i = 0; i < n_sizes; ++i)
+      for (int n : {bh[i], bw[i]}) {
+        if (seen[n]) continue;
+        seen[n] = 1;
+        t1_off[n] = (int32_t)t1.size();
+        for (int m = 0; m < n; ++m) t1.push_back(cos(2.0 * M_PI * (double)m / (double)n));
+        for (int m = 0; m < n; ++m) t1.push_back(sin(2.0 * M_PI * (double)m / (double)n));
+      }
+    HIPCHK(h, dup_device(&h->d_tab1d, t1.data(), t1.size(), st));
+    HIPCHK(h, dup_device(&h->d_t1_off, t1_off.data(), t1_off.size(), st));
+    HIPCHK(h, hipStreamSynchronize(st));       // the host vectors end with this block
+  }
   HIPCHK(h, hipStreamSynchronize(st));
   h->B.bh = h->d_bh; h->B.bw = h->d_bw; h->B.masks = h->d_masks; h->B.mask_off = h->d_mask_off;
   h->B.n_sizes = n_sizes; h->B.max_bh = max_bh; h->B.max_bw = max_bw;
@@ -486,6 +507,7 @@ static ProposeArgs make_propose(gsm_handle h, const gsm_rf_params* rf, int n_ste
   p.tables = h->d_tables; p.tables_len = h->tables_len; p.tab_max = h->tab_max; p.fy_off = h->d_fy_off; p.g_off = h->d_g_off;
   p.lds_sx = h->lds_sx; p.lds_st = h->lds_st; p.lds_x_half = h->lds_x_half; p.lds_tt = h->lds_tt;
   p.k2tab = h->d_k2; p.k2_off = h->d_k2_off; p.mathtab = h->d_mathtab;
+  p.tab1d = h->d_tab1d; p.t1_off = h->d_t1_off;
   p.lds_main = std::max(4 * h->lds_x_half, h->lds_tt);
   p.tiles1_max = h->prop_tiles1; p.tiles2_max = h->prop_tiles;
   return p;

@@ -90,6 +90,10 @@ struct PropScalars {
   // magic reciprocals (0xFFFFFFFF / d + 1) of the three divisors of a step -- half-plane columns bw/2 + 1, operand
   // columns M1, width of the window's halo tile -- so that no workgroup derives them with a uniform division
   uint32_t m_nc, m_m1, m_tw, reserved;
+  // strip kernel (chain_strip_kernel.hip): the DFT operand tables are 1-D twiddle tables in LDS, indexed by (k * j) mod n:
+  // magic reciprocals of the block height / width and the offsets of their [cos | sin](2 pi m / n) tables in ProposeArgs::tab1d
+  uint32_t m_bh, m_bw;
+  int32_t t1h_off, t1w_off;
 };
 
 struct ProposeArgs {
@@ -119,6 +123,8 @@ struct ProposeArgs {
   const double* mathtab;   // device copy of the table of math_tables.h (kMathTabDoubles doubles)
   int lds_main;            // max(4 * lds_x_half, lds_tt): T^T overlays X
   int tiles1_max, tiles2_max;  // largest stage-1 / stage-2 output-tile counts over the block table
+  const double* tab1d;     // per distinct block length n: cos(2 pi m / n), m < n, then sin(2 pi m / n)  (the values of `tables`)
+  const int32_t* t1_off;   // indexed by the length n: offset of its pair in tab1d
   const double* k2tab;     // (sqrt(kx^2 + ky^2) + 1e-10)^2 on ky <= bh/2, kx <= bw/2, one [nrow][ncol] table per block size
   const int32_t* k2_off;   // [n_sizes] offsets into k2tab
   PropScalars* scalars;    // device scratch, n_chains * n_steps records

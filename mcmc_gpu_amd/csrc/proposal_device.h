@@ -258,7 +258,14 @@ __device__ __forceinline__ void dma_to_lds(const double* __restrict__ src, doubl
 // Work unit = half an output tile: half 0 accumulates (Ur, Vi) = (Pr C, Mi S), which is all the real part of T^T
 // needs; half 1 accumulates (Ui, Vr) = (Pi C, Mr S) for the imaginary part.  Unit u goes to wave u mod NW.  Results wait
 // in registers until every wave has finished reading the planes, then overwrite them as T^T (tt_write).
-template <int NW, int UPW, bool TABLDS>
+// TABMODE: 0 = the [K][N] operand tables from global memory (L2), 1 = the same tables staged in LDS (tabA),
+// 2 = 1-D twiddle tables in LDS (tabA: cos(2 pi m / n) at [m], sin at [kT1S + m], n = block height), the operand of
+// (k, j) read at m = (k * j) mod n, advanced from one K step to the next by an add and a conditional subtract -- the
+// same numbers at 1 / 30 of the LDS footprint (chain_strip_kernel: two workgroups per CU).
+constexpr int kT1S = 128;    // doubles between the cos and the sin half of a 1-D table: block lengths up to 128
+__device__ __forceinline__ uint32_t mod_magic(uint32_t x, uint32_t n, uint32_t magic) { return x - __umulhi(x, magic) * n; }
+
+template <int NW, int UPW, int TABMODE>
 __device__ __forceinline__ void dft_stage1(const int w, const int lane, const ProposeArgs& a, const PropScalars& sc, const PropGeom& g,
                                            const double* plds, const double* tabA, v4f64 (&uc)[UPW], v4f64 (&us)[UPW]) {
   const int SX = g.SX, KR = g.KR, NR = g.NR;
@@ -283,10 +290,20 @@ __device__ __forceinline__ void dft_stage1(const int w, const int lane, const Pr
       const double* __restrict__ As = (u & 1) ? Mr : Mi;
       const double* fc_p = FC + l4 * NR + 16 * nt + l15;
       const double* fs_p = FS + l4 * NR + 16 * nt + l15;
+      // 1-D table: byte index of (k, y) = 8 * ((k * y) mod bh), stepping k by 4
+      const uint32_t n8 = 8u * (uint32_t)g.bh;
+      const uint32_t yy = mod_magic((uint32_t)(16 * nt + l15), (uint32_t)g.bh, sc.m_bh);
+      uint32_t m8 = 8u * mod_magic((uint32_t)l4 * yy, (uint32_t)g.bh, sc.m_bh);
+      const uint32_t d8 = 8u * mod_magic(4u * yy, (uint32_t)g.bh, sc.m_bh);
 #pragma unroll 2
       for (int k0 = 0; k0 < KR; k0 += 4) {
         double bc, bs;
-        if (TABLDS) {
+        if (TABMODE == 2) {
+          const char* tb = (const char*)tabA + m8;
+          bc = *(const double*)tb; bs = *(const double*)(tb + 8 * kT1S);
+          m8 += d8;
+          m8 = min(m8, m8 - n8);            // unsigned: m8 - n8 wraps to a huge value when m8 < n8
+        } else if (TABMODE == 1) {
           const int bo = (l4 + k0) * NR + 16 * nt + l15;
           bc = tabA[bo]; bs = tabA[KR * NR + bo];
         } else {
@@ -301,7 +318,9 @@ __device__ __forceinline__ void dft_stage1(const int w, const int lane, const Pr
   }
 }
 
-template <int NW, int UPW>
+// FOLD_CK: the rows kx of T^T are scaled by the Hermitian-half factor c_kx (1 for kx in {0, bw / 2}, else 2) here instead of
+// in the stage-2 operand table (TABMODE 2 reads plain cos / sin): (2 a) b and a (2 b) are the same product, exactly.
+template <int NW, int UPW, bool FOLD_CK = false>
 __device__ __forceinline__ void dft_tt_write(const int w, const int lane, const PropGeom& g, double* TT, const v4f64 (&uc)[UPW],
                                              const v4f64 (&us)[UPW]) {
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -321,8 +340,11 @@ __device__ __forceinline__ void dft_tt_write(const int w, const int lane, const 
         for (int q = 0; q < 4; ++q) {
           const int kx = 16 * mt + l4 + 4 * q;
           if (kx < Kc) {
-            Th[kx * ST + y] = (u & 1) ? uc[j][q] + us[j][q] : uc[j][q] - us[j][q];
-            if (y > 0 && y < hh) Th[kx * ST + (bh - y)] = (u & 1) ? uc[j][q] - us[j][q] : uc[j][q] + us[j][q];
+            double t1 = (u & 1) ? uc[j][q] + us[j][q] : uc[j][q] - us[j][q];
+            double t2 = (u & 1) ? uc[j][q] - us[j][q] : uc[j][q] + us[j][q];
+            if (FOLD_CK && kx != 0 && kx != g.hw) { t1 = 2.0 * t1; t2 = 2.0 * t2; }
+            Th[kx * ST + y] = t1;
+            if (y > 0 && y < hh) Th[kx * ST + (bh - y)] = t2;
           }
         }
       }
@@ -332,7 +354,8 @@ __device__ __forceinline__ void dft_tt_write(const int w, const int lane, const 
 
 // ---- stage 2 (MFMA): E = Tr^T Gc, O = Ti^T Gs on x in [0, hw]; results stay in registers -----------
 // tile t of the (N1/16) x (M1/16) output grid goes to wave t mod NW
-template <int NW, int MAXT, bool TABLDS>
+// TABMODE as in dft_stage1; 2: tabG = 1-D table of the block width, cos at [m], -sin at [kT1S + m]; T^T carries c_kx
+template <int NW, int MAXT, int TABMODE>
 __device__ __forceinline__ void dft_stage2(const int w, const int lane, const ProposeArgs& a, const PropScalars& sc, const PropGeom& g,
                                            const double* TT, const double* tabG, v4f64 (&fe)[MAXT], v4f64 (&fo)[MAXT]) {
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -350,10 +373,19 @@ __device__ __forceinline__ void dft_stage2(const int w, const int lane, const Pr
       const double* a_p = TT + l4 * ST + 16 * mt + l15;
       const double* gc_p = GC + l4 * M1 + 16 * nt + l15;
       const double* gs_p = GS + l4 * M1 + 16 * nt + l15;
+      const uint32_t n8 = 8u * (uint32_t)g.bw;
+      const uint32_t xx = mod_magic((uint32_t)(16 * nt + l15), (uint32_t)g.bw, sc.m_bw);
+      uint32_t m8 = 8u * mod_magic((uint32_t)l4 * xx, (uint32_t)g.bw, sc.m_bw);
+      const uint32_t d8 = 8u * mod_magic(4u * xx, (uint32_t)g.bw, sc.m_bw);
 #pragma unroll 2
       for (int k0 = 0; k0 < Kc; k0 += 4) {
         double gc, gs;
-        if (TABLDS) {
+        if (TABMODE == 2) {
+          const char* tb = (const char*)tabG + m8;
+          gc = *(const double*)tb; gs = *(const double*)(tb + 8 * kT1S);
+          m8 += d8;
+          m8 = min(m8, m8 - n8);
+        } else if (TABMODE == 1) {
           const int bo = (l4 + k0) * M1 + 16 * nt + l15;
           gc = tabG[bo]; gs = tabG[Kc * M1 + bo];
         } else {

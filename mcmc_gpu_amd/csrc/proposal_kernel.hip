@@ -63,6 +63,9 @@ __device__ __forceinline__ void block_shape(PropScalars& r, const ProposeArgs& a
   const int c0 = max(0, r.col - r.bw / 2), c1 = min(a.W, r.col + r.bw / 2);
   r.m_tw = pmagic((uint32_t)max(1, min(a.W, c1 + 1) - max(0, c0 - 1)));
   r.reserved = 0;
+  r.m_bh = pmagic((uint32_t)r.bh); r.m_bw = pmagic((uint32_t)r.bw);
+  r.t1h_off = a.t1_off ? a.t1_off[r.bh] : 0;
+  r.t1w_off = a.t1_off ? a.t1_off[r.bw] : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -99,18 +99,24 @@ __device__ __forceinline__ Window make_window(int H, int W, int row, int col, in
   return g;
 }
 
-// what a lane does in a step: fixed for the step
+// what a lane does in a step: fixed for the step.  The yes / no facts are bits of one register; a phase turns the ones it
+// needs into lane masks (scalar registers) for its own duration.
+enum : uint32_t {
+  kFValid = 1u,        // the lane's column exists (strip in use, column inside the grid and within the halo of the window)
+  kFColIn = 2u,        // ... and lies inside the window
+  kFColOwn = 4u,       // ... and is one of the strip's own columns
+  kFTopIn = 8u,        // the row of iteration 0 lies inside the window (a strip above owns it)
+  kFBelowIn = 16u,     // the row of iteration rows + 1 lies inside the window (a strip below owns it)
+  kFAtLeft = 32u, kFAtRight = 64u,   // border windows: the lane's column is grid column 0 / W - 1
+};
 struct Lane {
   uint32_t cell0;          // flat grid index of (row of iteration 0, the lane's column); wraps below zero for a border strip
   int fidx;                // index of that cell in the bh x bw proposal field (replay kernel: the field comes from HBM)
   int tidx;                // index of that cell in the LDS tile [(bh + 2)][bw + 2] (block cell (y, x) at (y + 1, x + 1))
   int rows;                // owned rows: iterations 1 .. rows (-2: the lane has nothing to do)
-  int hrows;               // iterations 1 .. hrows lie inside the window (rows, or rows + 1 when a strip follows below)
+  uint32_t flags;
   int lo, hi;              // border windows: iterations whose row exists and is needed: lo .. hi (hi < lo: none)
   int jtop, jbot;          // border windows: iteration of grid row 0 / H - 1
-  bool colin, colown;      // the lane's column lies inside the window / is one of the strip's own columns
-  bool topin;              // the row of iteration 0 lies inside the window
-  bool atleft, atright;    // border windows: the lane's column is grid column 0 / W - 1
 };
 __device__ __forceinline__ Lane lane_setup(const int lane, const int wave, const Cfg& c, const Window& g, const int H, const int W) {
   Lane L;
@@ -121,30 +127,30 @@ __device__ __forceinline__ Lane lane_setup(const int lane, const int wave, const
   const int wc = kc * (C - 2) + l - 1;                    // window column, -1 .. ww (halo columns included)
   const int gc = g.c0 + wc;
   int rows = min(c.n, g.wh - kr * c.n);
-  const bool colvalid = (kr < c.sr) && (rows > 0) && (wc <= g.ww) && (gc >= 0) && (gc < W);
-  if (!colvalid) rows = -2;
-  L.colin = colvalid && (wc >= 0) && (wc < g.ww);
-  L.colown = L.colin && (l >= 1) && (l <= C - 2);
+  const bool valid = (kr < c.sr) && (rows > 0) && (wc <= g.ww) && (gc >= 0) && (gc < W);
+  if (!valid) rows = -2;
+  const bool colin = valid && (wc >= 0) && (wc < g.ww);
+  const bool colown = colin && (l >= 1) && (l <= C - 2);
   const int wr0 = kr * c.n - 1;                           // window row of iteration 0
   const int gr0 = g.r0 + wr0;
   L.rows = rows;
-  L.hrows = rows + ((kr * c.n + rows < g.wh) ? 1 : 0);
-  L.topin = colvalid && (kr > 0);
+  L.flags = (valid ? kFValid : 0u) | (colin ? kFColIn : 0u) | (colown ? kFColOwn : 0u) | ((valid && kr > 0) ? kFTopIn : 0u) |
+            ((valid && kr * c.n + rows < g.wh) ? kFBelowIn : 0u) | ((gc == 0) ? kFAtLeft : 0u) | ((gc == W - 1) ? kFAtRight : 0u);
   L.lo = max(0, -gr0);
-  L.hi = colvalid ? min(rows + 1, H - 1 - gr0) : -1;
+  L.hi = valid ? min(rows + 1, H - 1 - gr0) : -1;
   L.jtop = -gr0; L.jbot = H - 1 - gr0;
   L.cell0 = (uint32_t)(gr0 * W + gc);
   L.fidx = (g.mr0 + wr0) * g.bw + g.mc0 + wc;
   L.tidx = (g.mr0 + wr0 + 1) * (g.bw + 2) + g.mc0 + wc + 1;
-  L.atleft = (gc == 0); L.atright = (gc == W - 1);
   return L;
 }
+__device__ __forceinline__ bool has(const Lane& L, const uint32_t f) { return (L.flags & f) != 0u; }
 
 // Row predicates are one 32-bit compare each.  Left alone, the compiler computes every one of them once per step and keeps
 // the lane masks (two scalar registers each, several per row) alive from the loads to the commit -- hundreds of spilled
-// SGPRs.  Every phase therefore works on a copy of the lane record whose row limits it cannot trace back.
+// SGPRs.  Every phase therefore works on a copy of the lane record whose contents it cannot trace back.
 __device__ __forceinline__ Lane fresh(Lane L) {
-  asm volatile("" : "+v"(L.rows), "+v"(L.hrows), "+v"(L.lo), "+v"(L.hi));
+  asm volatile("" : "+v"(L.rows), "+v"(L.flags), "+v"(L.lo), "+v"(L.hi));
   return L;
 }
 // The same for the grid width: jj * W * bytes-per-cell are invariants of the whole launch, and the compiler would keep all
@@ -172,27 +178,35 @@ __device__ __forceinline__ double ld_f64_s(rsrc_t r, uint32_t off, uint32_t soff
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, (int)soff, 0));
 }
 
-// Per-lane byte offset and uniform row offset of iteration jj in a plane of `cb` bytes per cell.  Interior windows: the
-// lane's offset is fixed and the row advances in the scalar offset of the instruction.  Border windows: cell0 may lie one
-// row above the grid (a negative, wrapped index), so the row term is added per lane and no offset is ever negative when
-// it is used.
+// Byte offset of the lane's cell of iteration jj in a plane of `cb` bytes per cell, as (per-lane part, uniform part).
+// Interior windows: the lane's part is fixed for the step and the row advances in the scalar offset of the instruction.
+// Border windows: cell0 may lie one row above the grid (a negative, wrapped index), so the row term is added per lane and no
+// offset is negative when it is used.
 template <bool INTERIOR>
 __device__ __forceinline__ void row_offsets(const Lane& L, const int jj, const int W, const uint32_t cb, uint32_t& off, uint32_t& soff) {
   if (INTERIOR) { off = L.cell0 * cb; soff = (uint32_t)(jj * W) * cb; }
   else { off = (L.cell0 + (uint32_t)(jj * W)) * cb; soff = 0u; }
 }
-// the row of iteration jj exists in the grid and the lane needs it
-template <bool INTERIOR>
-__device__ __forceinline__ bool row_needed(const Lane& L, const int jj) {
-  return INTERIOR ? (jj - 1 <= L.rows) : (jj >= L.lo && jj <= L.hi);
-}
-__device__ __forceinline__ bool row_in_window(const Lane& L, const int jj) { return (jj == 0) ? L.topin : (jj <= L.hrows); }
-__device__ __forceinline__ bool cell_own(const Lane& L, const int jj) { return (jj >= 1) && (jj <= kNR) && (jj <= L.rows) && L.colown; }
+// border windows: the row of iteration jj exists in the grid and the lane needs it
+__device__ __forceinline__ bool row_exists(const Lane& L, const int jj) { return jj >= L.lo && jj <= L.hi; }
+__device__ __forceinline__ bool row_own(const Lane& L, const int jj) { return (jj >= 1) && (jj <= kNR) && (jj <= L.rows); }
 // phase A writes the tile cell of iteration jj: the lane's own cells (candidate bed) and the cells of the halo ring around
-// the window (bed); cells inside the window that belong to another strip are that strip's to write
+// the window (bed); cells inside the window that belong to another strip are that strip's to write.  w0, w1, w2: the
+// answer for iteration 0, for the own rows, for iteration rows + 1 (lane masks, fixed for the step).
+struct WriteMasks { bool w0, w1, w2; };
+__device__ __forceinline__ WriteMasks write_masks(const Lane& L) {
+  WriteMasks m;
+  const bool valid = has(L, kFValid), colin = has(L, kFColIn);
+  m.w0 = valid && !(has(L, kFTopIn) && colin);
+  m.w1 = valid && (has(L, kFColOwn) || !colin);
+  m.w2 = valid && !(has(L, kFBelowIn) && colin);
+  return m;
+}
 template <bool INTERIOR>
-__device__ __forceinline__ bool cell_written(const Lane& L, const int jj) {
-  return row_needed<INTERIOR>(L, jj) && (cell_own(L, jj) || !(row_in_window(L, jj) && L.colin));
+__device__ __forceinline__ bool cell_written(const Lane& L, const WriteMasks& m, const int jj) {
+  bool w = (jj == 0) ? m.w0 : ((jj <= L.rows && m.w1) || (jj - 1 == L.rows && m.w2));
+  if (!INTERIOR) w = w && row_exists(L, jj);
+  return w;
 }
 
 // ---- phase A, part 1: every load of the chain state of the step, issued back to back --------------------------------
@@ -205,13 +219,15 @@ __device__ __forceinline__ void load_state(const Lane& L_in, const int n, const 
                                            double (&vb)[kNR + 2], double (&ve)[kNR], double2 (&a2)[kNA]) {
   const Lane L = fresh(L_in);
   const int W = fresh_s(W_in);
+  const WriteMasks wm = write_masks(L);
+  const bool colown = has(L, kFColOwn);
 #pragma unroll
   for (int jj = 0; jj < kNR + 2; ++jj) {
     vb[jj] = 0.0;
     if (jj <= n + 1) {
       uint32_t off, soff;
       row_offsets<INTERIOR>(L, jj, W, (uint32_t)sizeof(TS), off, soff);
-      vb[jj] = RowIO<TS>::load(r_bed, cell_written<INTERIOR>(L, jj) ? off : kOOB, soff);
+      vb[jj] = RowIO<TS>::load(r_bed, cell_written<INTERIOR>(L, wm, jj) ? off : kOOB, soff);
     }
   }
 #pragma unroll
@@ -220,7 +236,7 @@ __device__ __forceinline__ void load_state(const Lane& L_in, const int n, const 
     if (R <= n) {
       uint32_t off, soff;
       row_offsets<INTERIOR>(L, R, W, (uint32_t)sizeof(TS), off, soff);
-      ve[R - 1] = RowIO<TS>::load(r_en, cell_own(L, R) ? off : kOOB, soff);
+      ve[R - 1] = RowIO<TS>::load(r_en, (row_own(L, R) && colown) ? off : kOOB, soff);
     }
   }
 #pragma unroll
@@ -229,7 +245,7 @@ __device__ __forceinline__ void load_state(const Lane& L_in, const int n, const 
     if (R <= n) {
       uint32_t off, soff;
       row_offsets<INTERIOR>(L, R, W, 16u, off, soff);
-      a2[R - 1] = ld_f64x2(r_st, cell_own(L, R) ? off : kOOB, soff);
+      a2[R - 1] = ld_f64x2(r_st, (row_own(L, R) && colown) ? off : kOOB, soff);
     }
   }
 }
@@ -244,6 +260,8 @@ __device__ __forceinline__ void phase_a(const Lane& L_in, const int n, const int
   constexpr bool F32 = sizeof(TS) == 4;
   const Lane L = fresh(L_in);
   const int W = fresh_s(W_in);
+  const WriteMasks wm = write_masks(L);
+  const bool colown = has(L, kFColOwn);
   acc_old = 0.0;
 #pragma unroll
   for (int R = 1; R <= kNR; ++R) if (R <= n) acc_old += ve[R - 1];
@@ -255,14 +273,14 @@ __device__ __forceinline__ void phase_a(const Lane& L_in, const int n, const int
 #pragma unroll
   for (int jj = 0; jj < kNR + 2; ++jj) {
     if (jj <= n + 1) {
-      const bool own = cell_own(L, jj);
       double v = vb[jj];
       if (jj >= 1 && jj <= kNR) {
+        const bool own = row_own(L, jj) && colown;
         const double2 A2 = a2[(jj - 1) % kNA];
         if (jj + kNA <= kNR && jj + kNA <= n) {             // (wupd, surf) of row jj + kNA into the slot just read
           uint32_t off, soff;
           row_offsets<INTERIOR>(L, jj + kNA, W, 16u, off, soff);
-          a2[(jj - 1) % kNA] = ld_f64x2(r_st, cell_own(L, jj + kNA) ? off : kOOB, soff);
+          a2[(jj - 1) % kNA] = ld_f64x2(r_st, (row_own(L, jj + kNA) && colown) ? off : kOOB, soff);
         }
         const double f = field(jj, own);
         const bool upd = own && (__builtin_bit_cast(uint64_t, A2.x) != kNoUpdBits);
@@ -274,7 +292,7 @@ __device__ __forceinline__ void phase_a(const Lane& L_in, const int n, const int
         guard = guard || (upd && thick <= 0.0);
         upd_bits |= upd ? (1u << jj) : 0u;
       }
-      if (cell_written<INTERIOR>(L, jj)) tile[L.tidx + jj * ts] = v;
+      if (cell_written<INTERIOR>(L, wm, jj)) tile[L.tidx + jj * ts] = v;
     }
   }
 }
@@ -294,32 +312,40 @@ struct StepConsts { double res, rcp_res, two_res, rcp_two_res; };
 
 // ---- phase D: fluxes from the tile, residual stencil (Topography.py:592-600, np.gradient's one-sided differences at the
 // grid border), new energies -> en[R - 1] of the lane's own rows; acc_new = their sum.  Every lane of the wave must be here
-// (DPP).  The operands of row jj + 1 are requested before row jj is worked on.
+// (DPP).  The operands of row jj + 1 are requested before row jj is worked on.  Interior windows: every lane with a column
+// reads every row up to n + 1 -- rows past its own halo row give fluxes nobody uses -- so that no load carries a per-row
+// predicate: one register of per-lane offset, fixed for the step, and the row in the instruction's scalar offset.
 struct RowOps { double v, surf; double2 B2, C2; };
 template <typename TS, bool FAST_DIV, bool INTERIOR>
 struct PhaseD {
   const Lane& L; const int n, W, ts; const rsrc_t r_st; const uint32_t off_sB; const StepConsts& K; const double* __restrict__ tile;
+  const uint32_t off_v, off_o;      // interior: 16 * cell0 where the lane has a column / an own column, else out of range
+  const bool colown;
   double (&en)[kNR]; double acc_new;
   double qy_m2, qy_m1, qx_m1; double2 C_m1; bool own_m1;
 
   __device__ __forceinline__ RowOps request(const int jj) const {
     RowOps o;
-    uint32_t off, soff;
-    row_offsets<INTERIOR>(L, jj, W, 16u, off, soff);
-    const bool need = row_needed<INTERIOR>(L, jj);
-    o.v = need ? tile[L.tidx + jj * ts] : 0.0;
-    o.surf = ld_f64_s(r_st, need ? off + 8u : kOOB, soff);
-    o.B2 = ld_f64x2(r_st, need ? off : kOOB, soff + off_sB);
+    uint32_t ov, oo, soff;
+    if (INTERIOR) { ov = off_v; oo = off_o; soff = (uint32_t)(jj * W) * 16u; }
+    else {
+      const uint32_t off = (L.cell0 + (uint32_t)(jj * W)) * 16u;
+      const bool need = row_exists(L, jj);
+      ov = need ? off : kOOB; oo = (need && colown) ? off : kOOB; soff = 0u;
+    }
+    o.v = tile[L.tidx + jj * ts];
+    o.surf = ld_f64_s(r_st, ov + 8u, soff);
+    o.B2 = ld_f64x2(r_st, ov, soff + off_sB);
     o.C2 = make_double2(0.0, 0.0);
-    if (jj >= 1 && jj <= kNR) o.C2 = ld_f64x2(r_st, cell_own(L, jj) ? off : kOOB, soff + 2u * off_sB);
+    if (jj >= 1 && jj <= kNR) o.C2 = ld_f64x2(r_st, oo, soff + 2u * off_sB);
     return o;
   }
   template <int JJ>
   __device__ __forceinline__ void row(const RowOps cur) {
     constexpr bool F32 = sizeof(TS) == 4;
     if (JJ <= n + 1) {        // uniform; nested, not a sequence: the rolling values need no copies on the way out
-      RowOps nxt = cur;
-      if (JJ + 1 <= kNR + 1) { if (JJ + 1 <= n + 1) nxt = request(JJ + 1); }
+      RowOps nxt;
+      if constexpr (JJ + 1 <= kNR + 1) nxt = request(JJ + 1);
       const double thick = cur.surf - cur.v;
       const double qx = cur.B2.x * thick, qy = cur.B2.y * thick;
       if (JJ >= 2) {
@@ -334,10 +360,11 @@ struct PhaseD {
           if (FAST_DIV) { dx = exact_div(ddx, K.two_res, K.rcp_two_res); dy = exact_div(ddy, K.two_res, K.rcp_two_res); }
           else { dx = ddx / K.two_res; dy = ddy / K.two_res; }
         } else {
-          const bool xedge = L.atleft || L.atright;
+          const bool atleft = has(L, kFAtLeft), atright = has(L, kFAtRight);
+          const bool xedge = atleft || atright;
           const bool attop = (R == L.jtop), atbot = (R == L.jbot);
-          if (L.atleft) qxl = qx_m1;
-          if (L.atright) qxr = qx_m1;
+          if (atleft) qxl = qx_m1;
+          if (atright) qxr = qx_m1;
           if (attop) qya = qy_m1;
           if (atbot) qyb = qy_m1;
           const double ddx = qxr - qxl, ddy = qyb - qya;
@@ -356,7 +383,7 @@ struct PhaseD {
         en[R - 1] = e;
         acc_new += e;
       }
-      qy_m2 = qy_m1; qy_m1 = qy; qx_m1 = qx; C_m1 = cur.C2; own_m1 = cell_own(L, JJ);
+      qy_m2 = qy_m1; qy_m1 = qy; qx_m1 = qx; C_m1 = cur.C2; own_m1 = row_own(L, JJ) && colown;
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (JJ + 1 <= kNR + 1) row<JJ + 1>(nxt);
     }
@@ -370,20 +397,22 @@ __device__ __forceinline__ void phase_d(const Lane& L_in, const int n, const int
   const int W = fresh_s(W_in);
 #pragma unroll
   for (int R = 0; R < kNR; ++R) en[R] = 0.0;
-  PhaseD<TS, FAST_DIV, INTERIOR> P{L, n, W, bw + 2, r_st, off_sB, K, tile, en, 0.0, 0.0, 0.0, 0.0, make_double2(0.0, 0.0), false};
+  const bool colown = has(L, kFColOwn);
+  PhaseD<TS, FAST_DIV, INTERIOR> P{L, n, W, bw + 2, r_st, off_sB, K, tile,
+                                   has(L, kFValid) ? L.cell0 * 16u : kOOB, colown ? L.cell0 * 16u : kOOB, colown,
+                                   en, 0.0, 0.0, 0.0, 0.0, make_double2(0.0, 0.0), false};
   P.template row<0>(P.request(0));
   acc_new = P.acc_new;
 }
 
 // candidate bed of the lane's own cells, back from the tile (before the reduction's barrier: once a wave is past it, the next
-// step's proposal may overwrite the tile)
-__device__ __forceinline__ void read_candidate(const Lane& L, const int n, const int bw, const double* __restrict__ tile, const uint32_t upd_bits,
-                                               double (&vn)[kNR]) {
+// step's proposal may overwrite the tile).  Read for every row; only the cells that take the update are stored.
+__device__ __forceinline__ void read_candidate(const Lane& L, const int n, const int bw, const double* __restrict__ tile, double (&vn)[kNR]) {
   const int ts = bw + 2;
 #pragma unroll
   for (int R = 1; R <= kNR; ++R) {
     vn[R - 1] = 0.0;
-    if (R <= n) vn[R - 1] = ((upd_bits >> R) & 1u) ? tile[L.tidx + R * ts] : 0.0;
+    if (R <= n) vn[R - 1] = tile[L.tidx + R * ts];
   }
 }
 
@@ -395,13 +424,14 @@ __device__ __forceinline__ void commit(const Lane& L_in, const int n, const int 
                                        const double (&vn)[kNR], const double (&en)[kNR], const uint32_t upd_bits) {
   const Lane L = fresh(L_in);
   const int W = fresh_s(W_in);
+  const bool colown = has(L, kFColOwn);
 #pragma unroll
   for (int R = 1; R <= kNR; ++R) {
     if (R > n) continue;
     uint32_t off, soff;
     row_offsets<INTERIOR>(L, R, W, (uint32_t)sizeof(TS), off, soff);
     const bool upd = (upd_bits >> R) & 1u;
-    RowIO<TS>::store(r_en, cell_own(L, R) ? off : kOOB, soff, en[R - 1]);
+    RowIO<TS>::store(r_en, (row_own(L, R) && colown) ? off : kOOB, soff, en[R - 1]);
     RowIO<TS>::store(r_bed, upd ? off : kOOB, soff, vn[R - 1]);
     if (RS) {
       uint32_t off4, soff4;
