@@ -295,15 +295,36 @@ __device__ __forceinline__ void dft_stage1(const int w, const int lane, const Pr
       const uint32_t yy = mod_magic((uint32_t)(16 * nt + l15), (uint32_t)g.bh, sc.m_bh);
       uint32_t m8 = 8u * mod_magic((uint32_t)l4 * yy, (uint32_t)g.bh, sc.m_bh);
       const uint32_t d8 = 8u * mod_magic(4u * yy, (uint32_t)g.bh, sc.m_bh);
+      if (TABMODE == 2) {
+        // two K steps per iteration: eight operand reads in flight, then four MFMAs; KR / 4 may be odd: one step after the loop
+        auto operands = [&](const int k0, double& a1, double& a2, double& b1, double& b2) {
+          const char* tb = (const char*)tabA + m8;
+          const int o = ao + k0 * SX;
+          a1 = Ac[o]; a2 = As[o]; b1 = *(const double*)tb; b2 = *(const double*)(tb + 8 * kT1S);
+          m8 += d8;
+          m8 = min(m8, m8 - n8);            // unsigned: m8 - n8 wraps to a huge value when m8 < n8
+        };
+        int k0 = 0;
+        for (; k0 + 8 <= KR; k0 += 8) {
+          double a1, a2, b1, b2, a3, a4, b3, b4;
+          operands(k0, a1, a2, b1, b2);
+          operands(k0 + 4, a3, a4, b3, b4);
+          ac = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, ac, 0, 0, 0);
+          as = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, as, 0, 0, 0);
+          ac = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, ac, 0, 0, 0);
+          as = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, b4, as, 0, 0, 0);
+        }
+        if (k0 < KR) {
+          double a1, a2, b1, b2;
+          operands(k0, a1, a2, b1, b2);
+          ac = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, ac, 0, 0, 0);
+          as = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, as, 0, 0, 0);
+        }
+      } else {
 #pragma unroll 2
       for (int k0 = 0; k0 < KR; k0 += 4) {
         double bc, bs;
-        if (TABMODE == 2) {
-          const char* tb = (const char*)tabA + m8;
-          bc = *(const double*)tb; bs = *(const double*)(tb + 8 * kT1S);
-          m8 += d8;
-          m8 = min(m8, m8 - n8);            // unsigned: m8 - n8 wraps to a huge value when m8 < n8
-        } else if (TABMODE == 1) {
+        if (TABMODE == 1) {
           const int bo = (l4 + k0) * NR + 16 * nt + l15;
           bc = tabA[bo]; bs = tabA[KR * NR + bo];
         } else {
@@ -312,6 +333,7 @@ __device__ __forceinline__ void dft_stage1(const int w, const int lane, const Pr
         const int o = ao + k0 * SX;
         ac = __builtin_amdgcn_mfma_f64_16x16x4f64(Ac[o], bc, ac, 0, 0, 0);
         as = __builtin_amdgcn_mfma_f64_16x16x4f64(As[o], bs, as, 0, 0, 0);
+      }
       }
     }
     uc[j] = ac; us[j] = as;
@@ -377,15 +399,34 @@ __device__ __forceinline__ void dft_stage2(const int w, const int lane, const Pr
       const uint32_t xx = mod_magic((uint32_t)(16 * nt + l15), (uint32_t)g.bw, sc.m_bw);
       uint32_t m8 = 8u * mod_magic((uint32_t)l4 * xx, (uint32_t)g.bw, sc.m_bw);
       const uint32_t d8 = 8u * mod_magic(4u * xx, (uint32_t)g.bw, sc.m_bw);
+      if (TABMODE == 2) {
+        auto operands = [&](const int k0, double& a1, double& a2, double& b1, double& b2) {
+          const char* tb = (const char*)tabG + m8;
+          a1 = a_p[k0 * ST]; a2 = a_p[(Kc + k0) * ST]; b1 = *(const double*)tb; b2 = *(const double*)(tb + 8 * kT1S);
+          m8 += d8;
+          m8 = min(m8, m8 - n8);
+        };
+        int k0 = 0;
+        for (; k0 + 8 <= Kc; k0 += 8) {
+          double a1, a2, b1, b2, a3, a4, b3, b4;
+          operands(k0, a1, a2, b1, b2);
+          operands(k0 + 4, a3, a4, b3, b4);
+          ae = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, ae, 0, 0, 0);
+          ao = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, ao, 0, 0, 0);
+          ae = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, ae, 0, 0, 0);
+          ao = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, b4, ao, 0, 0, 0);
+        }
+        if (k0 < Kc) {
+          double a1, a2, b1, b2;
+          operands(k0, a1, a2, b1, b2);
+          ae = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, ae, 0, 0, 0);
+          ao = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, ao, 0, 0, 0);
+        }
+      } else {
 #pragma unroll 2
       for (int k0 = 0; k0 < Kc; k0 += 4) {
         double gc, gs;
-        if (TABMODE == 2) {
-          const char* tb = (const char*)tabG + m8;
-          gc = *(const double*)tb; gs = *(const double*)(tb + 8 * kT1S);
-          m8 += d8;
-          m8 = min(m8, m8 - n8);
-        } else if (TABMODE == 1) {
+        if (TABMODE == 1) {
           const int bo = (l4 + k0) * M1 + 16 * nt + l15;
           gc = tabG[bo]; gs = tabG[Kc * M1 + bo];
         } else {
@@ -393,6 +434,7 @@ __device__ __forceinline__ void dft_stage2(const int w, const int lane, const Pr
         }
         ae = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p[k0 * ST], gc, ae, 0, 0, 0);
         ao = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p[(Kc + k0) * ST], gs, ao, 0, 0, 0);
+      }
       }
     }
     fe[j] = ae; fo[j] = ao;
