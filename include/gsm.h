@@ -168,6 +168,20 @@ int gsm_draw_pcg64(gsm_handle h, int32_t n_steps, const gsm_rf_params* rf, uint6
                    const uint8_t* region_mask, int32_t* size_idx, int32_t* centre, double* u, double* rf_scalars,
                    double* noise_re, double* noise_im, double* nugget_field, int64_t field_stride, void* stream);
 
+/* The 'pcg64' draw mode with synthesis and step in ONE launch: per (chain, step) record r = c * n_steps + s of gsm_draw_pcg64's
+ * outputs, the proposal field is formed from the white-noise planes exactly as gsm_spectral_from_noise forms it (the same stage
+ * functions, bit-identical fields) and consumed by the Metropolis step exactly as gsm_run_replay consumes it, inside the
+ * workgroup that owns the chain -- the field never goes to HBM (chain_strip_kernel.hip, two chains per CU).  Results equal
+ * gsm_spectral_from_noise + gsm_run_replay on the same handle bit for bit (tests/test_gpu_pcg64.py).  Needs a block table that
+ * goes to the strip kernels (gsm_strip_active), else GSM_E_UNSUPPORTED.  nugget_field may be NULL (no nugget term).  Checks the
+ * size indices and centres on the device (GSM_E_DEVICE_DATA).  Synchronises `stream` before returning (error flag).
+ * Replaces: RandField.get_rfblock + spectral_synthesis_field + the loop body of chain_crf.run (MCMC.py:742-778, :176-254,
+ * :1247-1360) for draws that are the reference's own. */
+int gsm_run_noise(gsm_handle h, int32_t n_steps, void* beds, void* energy, uint32_t* resampled, double* loss_sum,
+                  const int32_t* size_idx, const int32_t* centre, const double* u, const double* rf_scalars,
+                  const gsm_rf_params* rf, const double* noise_re, const double* noise_im, const double* nugget_field,
+                  int64_t field_stride, double* loss, uint8_t* accept, void* stream);
+
 /* The spectral synthesis alone, fed with CALLER-SUPPLIED white noise instead of Philox draws: the value pin of the device
  * arithmetic against the reference's.  For field r of n_fields:
  *   size_idx   [dev, n_fields]                 block-table index -> shape (bh, bw)
@@ -259,7 +273,9 @@ int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* const* factor
  *                                       (H - 1, W - 1) if the radius-widening fallback is to work
  *   hw                                  search half-width in cells: ceil(radius / |x_axis[1] - x_axis[0]|), the half-width of the
  *                                       reference's circle stencil (neighbors.py:66-83) -- any value >= 1 (the reference's driver:
- *                                       30 km at 500 m = 60)
+ *                                       30 km at 500 m = 60).  The ring-by-ring search certifies a sector as complete from
+ *                                       per-ring counters kept for the first 64 rings; beyond ring 64 (hw > 64 with sparse data) a
+ *                                       sector completes only when its candidates are exhausted -- same result, more passes
  *   cell_off [dev, n_chains+1], cells [dev, total*2]   the (row, col) of each chain's cells in simulation order -- the
  *                                       caller's rng.shuffle (MCMC.py:128); every cell must lie inside the chain's window
  *   z        [dev, total]               one standard normal per listed cell (used only if the cell is simulated):
@@ -276,7 +292,8 @@ int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* const* factor
  * definite) where the reference calls numpy.linalg.lstsq (_krige.py:37): weights agree to about cond(Sigma) * 1e-16 relative,
  * not bit for bit.  lstsq(rcond=None) truncates singular values below eps * N * s_max; here a pivot below eps * N * max|diag|
  * ends the call with GSM_E_DEVICE_DATA ("singular kriging system") instead -- tested range: tests/test_gpu_sgs.py.
- * Ordinary kriging only: chain_sgs.run never passes ktype (MCMC.py:1599, :160-161), simple kriging (sk_solve) is not built.
+ * Ordinary kriging unless gsm_sgs_set_kriging selected simple kriging (sk_solve; chain_sgs.run itself never passes ktype,
+ * MCMC.py:1599, :160-161).
  * Synchronises the stream.
  * Replaces: sgs (MCMC.py:91-173), neighbors (gstatsim_custom/neighbors.py:4-64), ok_solve (gstatsim_custom/_krige.py:5-44). */
 int gsm_sgs_blocks(gsm_handle h, double* grids, const double* zcond, const int32_t* windows, const double* x_axis,

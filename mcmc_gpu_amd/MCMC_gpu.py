@@ -21,6 +21,7 @@ Two draw modes:
 from __future__ import annotations
 
 import math
+import os
 import sys
 import time
 from copy import deepcopy
@@ -674,7 +675,7 @@ def run_many_replay(chain, RF, initial_beds, rf_states, chain_states, n_iter, ch
     return out, rf_states, chain_states
 
 
-def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, batch=None, device=None, progress=False):
+def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, batch=None, device=None, progress=False, fused=None):
     """The 'pcg64' draw mode: run_many_replay with NO host draws.  Chain c's two NumPy generators (rf_states[c], chain_states[c]:
     `Generator.bit_generator.state` dicts of PCG64 generators) are advanced ON THE DEVICE, bit for bit as NumPy advances them
     (gsm_draw_pcg64: PCG64, the 32-bit half cache of integers(), Lemire's bounded integers, uniform, the ziggurat normal), in
@@ -682,7 +683,9 @@ def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, bat
     value-pinned to the reference's spectral_synthesis_field at 1e-12 x scale) and the fields through gsm_run_replay.  Same
     return value as run_many_replay.  Against the CPU reference on the same seeds: block records, the draws and the final
     generator states are identical; accept masks are identical unless an accept uniform falls within ~1e-12 of its threshold;
-    beds and losses agree to the accuracy of the device's inverse DFT against pocketfft (tests/test_gpu_pcg64.py)."""
+    beds and losses agree to the accuracy of the device's inverse DFT against pocketfft (tests/test_gpu_pcg64.py).
+    fused (default: whenever the block table goes to the strip kernels): synthesis and step in ONE kernel per batch
+    (gsm_run_noise: the field never leaves the CU) -- bit-identical to the two calls."""
     import ctypes as C
     import torch
     from .engine import GsmEngine, _ptr
@@ -706,6 +709,10 @@ def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, bat
         d_reg = (torch.as_tensor(np.ascontiguousarray(np.asarray(chain.region_mask) == 1, dtype=np.uint8)).to(dev)
                  if chain.update_in_region else None)
         stride = eng.field_stride
+        if fused is None:
+            fused = eng.strip_active() and os.environ.get("GSM_PCG64_FUSED", "1") != "0"
+        elif fused and not eng.strip_active():
+            raise NotImplementedError("run_many_pcg64(fused=True): this block table does not go to the strip kernels")
         if batch is None:      # two sets of three noise planes + the fields of a batch: at most ~16 GiB
             batch = int(max(1, min(256, (16 << 30) // (7 * n_chains * stride * 8))))
         batch = max(1, min(int(batch), max(n_steps, 1)))
@@ -715,7 +722,7 @@ def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, bat
         si_all = torch.empty((n_chains, n_al), dtype=torch.int32, device=dev)
         blocks = np.zeros((n_chains, n_steps, 4))
         ce_all = torch.empty((n_chains, n_al, 2), dtype=torch.int32, device=dev)
-        fields = torch.zeros((n_chains, batch, stride), dtype=torch.float64, device=dev)
+        fields = None if fused else torch.zeros((n_chains, batch, stride), dtype=torch.float64, device=dev)
         nug = p.nugget_max > 0.0
         bufs = [eng.alloc_pcg64_buffers(batch, nug), eng.alloc_pcg64_buffers(batch, nug)]
         # Two streams: the draws of batch k + 1 (one wavefront per chain: latency-bound, leaves most of the chip idle) run beside the
@@ -744,15 +751,21 @@ def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, bat
             nxt = draw(k + 1) if k + 1 < len(sizes) else None
             with torch.cuda.stream(s_step):
                 s_step.wait_event(ev_drawn[k & 1])
-                fl = fields if n == batch else torch.zeros((n_chains, n, stride), dtype=torch.float64, device=dev)
                 l_b = torch.empty((n_chains, n), dtype=torch.float64, device=dev)
                 a_b = torch.empty((n_chains, n), dtype=torch.uint8, device=dev)
-                eng._check(eng.lib.gsm_spectral_from_noise(eng.h, n_chains * n, _ptr(d['size_idx']), _ptr(d['rf_scalars']), C.byref(p),
-                                                           _ptr(d['noise_re']), _ptr(d['noise_im']), _ptr(d['nugget']), _ptr(fl), stride,
-                                                           eng._stream()))
-                eng._check(eng.lib.gsm_run_replay(eng.h, n, _ptr(eng.beds), _ptr(eng.energy), _ptr(eng.resampled), _ptr(eng.loss_sum),
-                                                  _ptr(d['size_idx']), _ptr(d['centre']), _ptr(d['u']), _ptr(fl), stride,
-                                                  _ptr(l_b), _ptr(a_b), eng._stream()))
+                if fused:
+                    eng._check(eng.lib.gsm_run_noise(eng.h, n, _ptr(eng.beds), _ptr(eng.energy), _ptr(eng.resampled), _ptr(eng.loss_sum),
+                                                     _ptr(d['size_idx']), _ptr(d['centre']), _ptr(d['u']), _ptr(d['rf_scalars']), C.byref(p),
+                                                     _ptr(d['noise_re']), _ptr(d['noise_im']), _ptr(d['nugget']), stride,
+                                                     _ptr(l_b), _ptr(a_b), eng._stream()))
+                else:
+                    fl = fields if n == batch else torch.zeros((n_chains, n, stride), dtype=torch.float64, device=dev)
+                    eng._check(eng.lib.gsm_spectral_from_noise(eng.h, n_chains * n, _ptr(d['size_idx']), _ptr(d['rf_scalars']), C.byref(p),
+                                                               _ptr(d['noise_re']), _ptr(d['noise_im']), _ptr(d['nugget']), _ptr(fl), stride,
+                                                               eng._stream()))
+                    eng._check(eng.lib.gsm_run_replay(eng.h, n, _ptr(eng.beds), _ptr(eng.energy), _ptr(eng.resampled), _ptr(eng.loss_sum),
+                                                      _ptr(d['size_idx']), _ptr(d['centre']), _ptr(d['u']), _ptr(fl), stride,
+                                                      _ptr(l_b), _ptr(a_b), eng._stream()))
                 loss[:, done:done + n] = l_b
                 acc[:, done:done + n] = a_b
                 si_all[:, done:done + n] = d['size_idx']

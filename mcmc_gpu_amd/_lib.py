@@ -196,6 +196,7 @@ def load() -> C.CDLL:
     lib.gsm_run_replay.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]
     lib.gsm_propose_philox.argtypes = [vp, i32, i64, vp, C.POINTER(RfParams), vp, vp, vp, vp, i64, vp, vp]
     lib.gsm_spectral_from_noise.argtypes = [vp, i32, vp, vp, C.POINTER(RfParams), vp, vp, vp, vp, i64, vp]
+    lib.gsm_run_noise.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(RfParams), vp, vp, vp, i64, vp, vp, vp]
     lib.gsm_run_philox.argtypes = [vp, i32, i64, i32, vp, C.POINTER(RfParams), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsm_enable_timing.argtypes = [vp, i32]
     lib.gsm_set_fused.argtypes = [vp, i32]

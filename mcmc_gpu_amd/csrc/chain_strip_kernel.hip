@@ -83,7 +83,9 @@ __device__ __forceinline__ bool decide(const double sd, const double s_hi, const
   return u <= p_acc;
 }
 
-template <typename TS, bool FAST_DIV>
+// NOISE: the coefficients are formed from caller-supplied white-noise planes (the reference's own draws, advanced on the device
+// by gsm_draw_pcg64) instead of Philox draws: gsm_run_noise, the 'pcg64' draw mode with synthesis and step in one kernel.
+template <typename TS, bool FAST_DIV, bool NOISE>
 __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa) {
   typedef const __attribute__((address_space(4))) FusedArgs* cargs_t;
   auto kargs = [] { cargs_t p = (cargs_t)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p)); return p; };
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
   const double two_sigma2 = fa.T.S.two_sigma2, rcp_two_sigma2 = fa.T.S.rcp_two_sigma2;
   const uint32_t n_cells = (uint32_t)gH * (uint32_t)gW;
   const srec_t rec0 = (srec_t)(uintptr_t)(fa.P.scalars + (size_t)chain * fa.P.n_steps);
-  const uint64_t seed = fa.P.seeds[chain];
+  const uint64_t seed = NOISE ? 0ull : fa.P.seeds[chain];
   const int dbg = fa.P.dbg;      // diagnostics only (GSM_PROPOSE_DBG): 128 / 256 / 512 / 1024 skip phase D / phase A / the state loads / the commit
   for (int i = tid; i < kMathTabDoubles; i += kST) mtab[i] = fa.P.mathtab[i];
   if (tid < 16) red[tid] = 0.0;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
   }
   __syncthreads();
   int pr0 = 0, pr1 = 0, pc0 = 0, pc1 = 0;      // window of the previous step if it was accepted, else empty
-  const NoiseIn no_noise{nullptr, nullptr, nullptr};
+  const int64_t noise0 = NOISE ? (int64_t)chain * fa.P.n_steps * fa.noise_stride : 0;     // this chain's first record's planes
   auto prop_rec = [&](srec_t r) {
     PropScalars q;
     q.scale = r->scale; q.nug = r->nug; q.aa = r->aa; q.m_const = r->m_const; q.m_kappa = r->m_kappa;
@@ -153,7 +155,14 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
       const ProposeArgs pa = load_cs(&K->P);
       const PropScalars q = prop_rec(rec);
       const PropGeom pg = prop_geom(pa, q.bh, q.bw);
-      coef_items<kST, false>(ptid, 0, pg.nrow * pg.ncol, true, pa, q, pg, seed, pa.step0 + s, lds, pa.lds_x_half, no_noise, mtab);
+      NoiseIn nz{nullptr, nullptr, nullptr};
+      if (NOISE) {
+        typedef const __attribute__((address_space(4))) FusedArgs* cfa_t;
+        const cfa_t F = (cfa_t)K;
+        const int64_t o = noise0 + (int64_t)s * F->noise_stride;
+        nz.re = F->noise_re + o; nz.im = F->noise_im + o;
+      }
+      coef_items<kST, NOISE>(ptid, 0, pg.nrow * pg.ncol, true, pa, q, pg, seed, pa.step0 + s, lds, pa.lds_x_half, nz, mtab);
     }
     // Stores of an accepted step must have landed before a later step reads an overlapping window.  They were issued a
     // whole coefficient phase ago; the wait is free, and the barriers that follow order it across the waves.
@@ -196,12 +205,19 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
       mask_prefetch<kSW, kSMAXT>(wave, ln, pa, q, pg, mreg);
       double mean;
       const double gain = standardise<kSW, kSMAXT>(wave, ln, q, pg, dc0, red2, fe, fo, mean);     // contains a barrier
-      const bool with_nugget = pa.rf.nugget_max > 0.0;
+      NoiseIn nz{nullptr, nullptr, nullptr};
+      if (NOISE) {
+        typedef const __attribute__((address_space(4))) FusedArgs* cfa_t;
+        const cfa_t F = (cfa_t)K;
+        const double* nb = F->noise_nug;
+        if (nb) nz.nug = nb + noise0 + (int64_t)s * F->noise_stride;
+      }
+      const bool with_nugget = NOISE ? (nz.nug != nullptr) : (pa.rf.nugget_max > 0.0);
       emit_field<kSW, kSMAXT, true>(wave, ln, pa, q, pg, fe, fo, mreg, mean, gain, with_nugget, lds, [bw](int y, int x) { return (y + 1) * (bw + 2) + x + 1; });
       if (with_nugget) {
         __syncthreads();
         relaunder();
-        nugget_pass<kST, false>(ptid, pa, q, pg, seed, pa.step0 + s, no_noise, lds, [bw](int y, int x) { return (y + 1) * (bw + 2) + x + 1; }, mtab);
+        nugget_pass<kST, NOISE>(ptid, pa, q, pg, seed, pa.step0 + s, nz, lds, [bw](int y, int x) { return (y + 1) * (bw + 2) + x + 1; }, mtab);
       }
     }
     // ---- the step: strip geometry, chain state -> registers, pass, reduce, decide, commit -------------------------------------
@@ -421,11 +437,11 @@ hipError_t launch_step_strip(const StepArgs& a, hipStream_t st) {
   return a.f32_state ? launch_step_strip_t<float>(a, st) : launch_step_strip_t<double>(a, st);
 }
 
-template <typename TS>
+template <typename TS, bool NOISE>
 static hipError_t launch_fused_strip_t(const FusedArgs& a, hipStream_t st) {
   const size_t lds = fused_strip_lds_doubles(a) * sizeof(double);
-  auto kfast = chain_strip_kernel<TS, true>;
-  auto kslow = chain_strip_kernel<TS, false>;
+  auto kfast = chain_strip_kernel<TS, true, NOISE>;
+  auto kslow = chain_strip_kernel<TS, false, NOISE>;
   static bool attr_set[kMaxDevices] = {};
   int attr_dev;
   if (attr_needed_on_this_device(attr_set, attr_dev)) {
@@ -447,7 +463,17 @@ hipError_t launch_chain_strip(const FusedArgs& a_in, hipStream_t st) {
   { static int dbg = -1; if (dbg < 0) { const char* v = getenv("GSM_PROPOSE_DBG"); dbg = v ? atoi(v) : 0; } a.P.dbg = dbg; }   // diagnostics only
   a.work_len = strip_main_len(a);
   a.fld_len = 0;
-  return a.T.f32_state ? launch_fused_strip_t<float>(a, st) : launch_fused_strip_t<double>(a, st);
+  return a.T.f32_state ? launch_fused_strip_t<float, false>(a, st) : launch_fused_strip_t<double, false>(a, st);
+}
+
+// gsm_run_noise: launch_noise_chain_scalars must have filled a.P.scalars
+hipError_t launch_chain_strip_noise(const FusedArgs& a_in, hipStream_t st) {
+  if (!a_in.T.strip || a_in.P.tab_max <= 0 || !a_in.noise_re || !a_in.noise_im) return hipErrorInvalidValue;
+  FusedArgs a = a_in;
+  a.P.dbg = 0;
+  a.work_len = strip_main_len(a);
+  a.fld_len = 0;
+  return a.T.f32_state ? launch_fused_strip_t<float, true>(a, st) : launch_fused_strip_t<double, true>(a, st);
 }
 
 }  // namespace gsm

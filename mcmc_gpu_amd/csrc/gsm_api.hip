@@ -571,6 +571,49 @@ extern "C" int gsm_spectral_from_noise(gsm_handle h, int32_t n_fields, const int
   return GSM_OK;
 }
 
+extern "C" int gsm_run_noise(gsm_handle h, int32_t n_steps, void* beds, void* energy, uint32_t* resampled, double* loss_sum,
+                             const int32_t* size_idx, const int32_t* centre, const double* u, const double* rf_scalars,
+                             const gsm_rf_params* rf, const double* noise_re, const double* noise_im, const double* nugget_field,
+                             int64_t field_stride, double* loss, uint8_t* accept, void* stream) {
+  if (!h) return GSM_E_ARG;
+  if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_run_noise: call gsm_set_static first");
+  if (!h->have_blocks || !h->d_masks) return fail(h, GSM_E_STATE, "gsm_run_noise: call gsm_set_blocks with edge masks first");
+  if (!rf) return fail(h, GSM_E_ARG, "gsm_run_noise: rf is NULL");
+  gsm_rf_params rfs = *rf;
+  rfs.generator = GSM_GEN_SPECTRAL;
+  const bool had_centres = h->have_centres;
+  h->have_centres = true;                      // the centres arrive with the draws
+  int rc = check_propose_ready(h, &rfs, "gsm_run_noise");
+  h->have_centres = had_centres;
+  if (rc) return rc;
+  if (!strip_for(h)) return fail(h, GSM_E_UNSUPPORTED, "gsm_run_noise: this block table does not go to the strip kernels (gsm_strip_active); "
+                                                       "use gsm_spectral_from_noise + gsm_run_replay");
+  if (n_steps < 0 || n_steps > 65535) return fail(h, GSM_E_ARG, "gsm_run_noise: n_steps must be in [0, 65535]");
+  if (n_steps == 0) return GSM_OK;
+  if (!beds || !energy || !resampled || !loss_sum || !size_idx || !centre || !u || !rf_scalars || !noise_re || !noise_im || !loss || !accept)
+    return fail(h, GSM_E_ARG, "gsm_run_noise: NULL pointer");
+  if (field_stride < (int64_t)h->B.max_bh * h->B.max_bw) return fail(h, GSM_E_ARG, "gsm_run_noise: field_stride smaller than the largest block");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  { int rc2 = ensure_scalars(h, 0, (size_t)h->n_chains * n_steps); if (rc2) return rc2; }
+  { int rc2 = ensure_k2(h, &rfs, st); if (rc2) return rc2; }
+  FusedArgs fa{};
+  StepArgs& a = fa.T;
+  a.S = h->S; a.B = h->B;
+  a.n_chains = h->n_chains; a.n_steps = n_steps; a.tile_cap = h->tile_cap; a.strip = 1;
+  a.beds = beds; a.energy = energy; a.f32_state = h->f32_state; a.resampled = resampled; a.loss_sum = loss_sum;
+  a.loss = loss; a.accept = accept; a.blocks = nullptr;
+  a.rec_stride = n_steps; a.rec_offset = 0; a.in_stride = n_steps;
+  a.err_flag = h->d_err;
+  fa.P = make_propose(h, &rfs, n_steps, 0, nullptr);
+  fa.P.scalars = h->d_scalars[0];
+  fa.noise_re = noise_re; fa.noise_im = noise_im; fa.noise_nug = nugget_field; fa.noise_stride = field_stride;
+  HIPCHK(h, launch_noise_chain_scalars(fa.P, size_idx, centre, u, rf_scalars, h->d_err, st));
+  HIPCHK(h, launch_chain_strip_noise(fa, st));
+  HIPCHK(h, launch_resampled_from_records(fa, st));
+  return check_device_flag(h, st, "gsm_run_noise");
+}
+
 extern "C" int gsm_last_run_fused(gsm_handle h) { return h ? h->last_fused : GSM_E_ARG; }
 
 extern "C" int gsm_set_fused(gsm_handle h, int32_t on) {

@@ -136,6 +136,10 @@ struct FusedArgs {
   StepArgs T;
   ProposeArgs P;
   int work_len, fld_len;   // LDS region sizes in doubles, set by launch_chain_fused
+  // gsm_run_noise (chain_strip_kernel<NOISE>): caller-supplied white noise instead of Philox draws -- record r's planes at
+  // r * noise_stride (row-major (bh, bw)); noise_nug NULL: no nugget term
+  const double* noise_re; const double* noise_im; const double* noise_nug;
+  int64_t noise_stride;
 };
 
 // scratch + factor table of the Cholesky proposal generator (cholesky_kernel.hip)
@@ -261,6 +265,9 @@ hipError_t launch_spectral_from_noise(const ProposeArgs& a, const int32_t* size_
                                       const double* noise_im, const double* nugget_field, hipStream_t st);
 hipError_t launch_chain_fused(const FusedArgs& a, hipStream_t st);
 hipError_t launch_chain_strip(const FusedArgs& a, hipStream_t st);
+hipError_t launch_chain_strip_noise(const FusedArgs& a, hipStream_t st);
+hipError_t launch_noise_chain_scalars(const ProposeArgs& a, const int32_t* size_idx, const int32_t* centre, const double* u,
+                                      const double* rf_scalars, int32_t* err_flag, hipStream_t st);
 hipError_t launch_step_strip(const StepArgs& a, hipStream_t st);
 hipError_t launch_resampled_from_records(const FusedArgs& a, hipStream_t st);
 bool strip_table_ok(const StaticFields& S, const BlockTable& B, int lds_main, int tiles1_max, int tiles2_max);

@@ -163,6 +163,32 @@ __global__ __launch_bounds__(256) void noise_scalars_kernel(const ProposeArgs a,
   a.scalars[rec] = r;
 }
 
+// gsm_run_noise: the same plus the step's block centre and accept uniform -- the records chain_strip_kernel<NOISE> reads
+__global__ __launch_bounds__(256) void noise_chain_scalars_kernel(const ProposeArgs a, const int32_t* __restrict__ size_idx,
+                                                                  const int32_t* __restrict__ centre, const double* __restrict__ u,
+                                                                  const double* __restrict__ rf_scalars, int32_t* __restrict__ err_flag) {
+  const int64_t rec = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (rec >= (int64_t)a.n_chains * a.n_steps) return;
+  PropScalars r;
+  r.si = size_idx[rec]; r.row = centre[2 * rec]; r.col = centre[2 * rec + 1];
+  if (r.si < 0 || r.si >= a.B.n_sizes || r.row < 0 || r.row >= a.H || r.col < 0 || r.col >= a.W) {
+    atomicExch(err_flag, 1);                 // reported by the host wrapper after the launch; the step runs on a valid stand-in
+    r.si = 0; r.row = 0; r.col = 0;
+  }
+  r.scale = rf_scalars[4 * rec]; r.nug = rf_scalars[4 * rec + 1];
+  r.range_x = rf_scalars[4 * rec + 2]; r.range_y = rf_scalars[4 * rec + 3];
+  r.u = u[rec];
+  spectral_params(r, a.rf);
+  block_shape(r, a);
+  a.scalars[rec] = r;
+}
+hipError_t launch_noise_chain_scalars(const ProposeArgs& a, const int32_t* size_idx, const int32_t* centre, const double* u,
+                                      const double* rf_scalars, int32_t* err_flag, hipStream_t st) {
+  const int64_t nrec = (int64_t)a.n_chains * a.n_steps;
+  hipLaunchKernelGGL(noise_chain_scalars_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, st, a, size_idx, centre, u, rf_scalars, err_flag);
+  return hipGetLastError();
+}
+
 // ... and the synthesis itself: propose_field with the coefficients formed from the caller's noise planes
 template <int WIDE>
 __global__ __launch_bounds__(512, (WIDE == 1) ? 2 : 1) void spectral_from_noise_kernel(const ProposeArgs a, const double* __restrict__ noise_re,

@@ -1,8 +1,8 @@
 """Chain sharding across the GPUs of one node: one process per GPU, torch.distributed over RCCL/xGMI.
 
 The reference's only parallelism is one chain per OS process (mp.Pool.starmap,
-largeScaleChain_multiprocessing_GPU.py:84-85); chains never communicate.  Here chain c of n_chains goes to
-rank c // ceil(n_chains / world) (contiguous shards), the step loop runs with no collective at all, and the
+largeScaleChain_multiprocessing_GPU.py:84-85); chains never communicate.  Here every rank owns one contiguous shard of the chains -- floor(n_chains / world)
+of them, the first n_chains % world ranks one more (shard_bounds) -- the step loop runs with no collective at all, and the
 per-chain results are all-gathered once per segment, after the loop.
 """
 from __future__ import annotations

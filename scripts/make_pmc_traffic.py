@@ -19,7 +19,7 @@ F, Wr = mean_per_kernel([fetch_dir], 'FETCH_SIZE'), mean_per_kernel([write_dir],
 work = [json.loads(l) for l in open(log) if l.startswith('{')]
 plane = work[0]['plane_bytes']
 copy = [k for k in F if 'stream_copy' in k][0]
-fused = [k for k in F if 'chain_fused_kernel' in k][0]
+fused = [k for k in F if 'chain_fused_kernel' in k or 'chain_strip_kernel' in k][0]      # whichever chain kernel the handle ran
 f_fetch = plane / (F[copy] * 1024)
 f_write = plane / (Wr[copy] * 1024)
 alg = sum(w['algorithmic_bytes_launch'] for w in work) / len(work)
@@ -29,9 +29,16 @@ try:
 except Exception:
     commit = None
 import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+try:                                   # the GPU box has no .git: the library's source hash identifies the build there
+    from mcmc_gpu_amd import _lib
+    src_hash = _lib.source_hash()
+except Exception:
+    src_hash = None
 res = {
     "grid": 256, "chains": 1024, "state": "f64", "steps_per_launch": work[0]['steps'],
-    "commit": os.environ.get("GSM_COMMIT") or commit,
+    "commit": os.environ.get("GSM_COMMIT") or commit or (("src:" + src_hash) if src_hash else None),
+    "source_hash": src_hash,
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over scripts/pmc_fused.py; KiB units; "
               "read side multiplied by the factor measured on gsm::stream_copy_kernel (known 512 MiB)",
     "calibration": {"kernel": copy, "known_bytes": plane, "FETCH_SIZE_KiB": F[copy], "WRITE_SIZE_KiB": Wr[copy],
@@ -52,7 +59,7 @@ if sq_dirs:
             sq[c] = m[fused]
     res["sq_counters_per_launch"] = sq
     if "SQ_WAVE_CYCLES" in sq and "SQ_ACTIVE_INST_VALU" in sq:
-        waves_per_simd = 4   # one 1024-thread workgroup per CU
+        waves_per_simd = 4   # one 1024-thread workgroup or two 512-thread workgroups per CU
         # SQ_WAVE_CYCLES and SQ_ACTIVE_INST_* count quad-cycles per wave; a SIMD executes one VALU instruction at a time
         res["valu_busy_frac_per_simd"] = waves_per_simd * sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]
         res["mfma_busy_frac_per_simd"] = sq.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (sq["SQ_WAVE_CYCLES"] * 4 / waves_per_simd)

@@ -128,6 +128,31 @@ def test_pcg64_batches_equal_host_replay_at_headline_geometry():
     assert 0.3 < np.mean([x[4][1:].mean() for x in a]) < 0.8
 
 
+@pytest.mark.parametrize("H,blocks,isotropic,nugget_max", [(256, (50, 80), True, 0.0), (96, (20, 40), False, 4.0)])
+def test_fused_synthesis_and_step_equal_the_two_calls(H, blocks, isotropic, nugget_max):
+    """gsm_run_noise (synthesis + step in one kernel, the field never leaving the CU) against gsm_spectral_from_noise +
+    gsm_run_replay on the same device draws: every output bit for bit (beds, losses, accept masks, resampled counts, generator
+    states) -- the same stage functions form the field, the same strip functions take the step."""
+    from mcmc_gpu_amd import MCMC_gpu, synthetic
+    prob, ch, _ = synthetic.template(H)
+    rf = MCMC_gpu.RandField(10e3, 50e3, 12e3, 40e3, 50, 150, nugget_max, "Matern", isotropic, smoothness=0.9125)
+    rf.set_block_sizes(blocks[0], blocks[1], blocks[0], blocks[1])
+    rf.set_weight_param(2, 0, 6, 1, 49900.0, prob["resolution"])
+    rf.set_generation_method(True)
+    ch.set_crf_data_weight(rf)
+    n = 6
+    beds = np.stack(list(synthetic.initial_beds(prob, n)))
+    st = [np.random.default_rng(seed=500 + i).bit_generator.state for i in range(n)]
+    a, rf_a, ch_a = MCMC_gpu.run_many_pcg64(ch, rf, beds, st, st, 81, batch=32, fused=True)
+    b, rf_b, ch_b = MCMC_gpu.run_many_pcg64(ch, rf, beds, st, st, 81, batch=32, fused=False)
+    assert rf_a == rf_b and ch_a == ch_b
+    for x, y in zip(a, b):
+        for k in (0, 3, 4, 5):
+            assert np.array_equal(x[k], y[k]), k
+        assert np.array_equal(x[6], y[6], equal_nan=True)
+    assert 0.2 < np.mean([x[4][1:].mean() for x in a]) < 0.95
+
+
 def test_small_scale_device_draws_equal_numpy():
     """gsm_sgs_draw_pcg64 against the host mirror's NumPy calls (chain_sgs_gpu._draw_iteration: centre, block sizes, rng.shuffle,
     one normal per cell without data, rng.random -- MCMC.py:1750-1757, :128, :165, :1797): windows, visiting orders, normals,
