@@ -401,15 +401,29 @@ def measure_pcg64_mode(H=256, n_chains=1024, n_steps=2048):
     st = [np.random.default_rng(seed=7 + i).bit_generator.state for i in range(n_chains)]
     MCMC_gpu.run_many_pcg64(ch, rf, beds[:8], st[:8], st[:8], 9)                    # warm-up
     t0 = time.perf_counter()
-    out, _, _ = MCMC_gpu.run_many_pcg64(ch, rf, beds, st, st, n_steps + 1)
+    tm = {}
+    out, _, _ = MCMC_gpu.run_many_pcg64(ch, rf, beds, st, st, n_steps + 1, timing=tm)
     dt = time.perf_counter() - t0
+    loop = tm["loop_seconds"]
+    blocks = np.stack([o[6][1:] for o in out]).astype(np.int64)          # (chains, steps, 4): row, col, bh, bw
+    acc = np.stack([o[4][1:] for o in out]).astype(np.int64)
+    alg = algorithmic_bytes(blocks, acc, H, H)
+    rate = n_chains * n_steps / loop
     return {"metric": f"chain-steps/sec on {H}x{H} grid x {n_chains} chains in the 'pcg64' draw mode",
-            "value": n_chains * n_steps / dt, "unit": "chain-steps/s", "n_gpus": 1, "dtype": "f64", "data": "synthetic",
+            "value": rate, "unit": "chain-steps/s", "n_gpus": 1, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"largeScaleChain {H}x{H} grid, {n_chains} chains, fp64, NumPy PCG64 streams of the reference advanced on the "
                                    "device (draws, block records, accept masks and generator states of the CPU reference on the same seeds), "
-                                   "blocks 50-80, sigma_mc 5", "steps": n_steps},
-            "accept_rate": float(np.mean([o[4][1:].mean() for o in out])), "timed_seconds": dt,
-            "note": "host-drawn replay mode on the same box: 25-41 k chain-steps/s with 15 draw workers (scripts/replay_batch_bench.py)"}
+                                   "blocks 50-80, sigma_mc 5", "steps": n_steps, "steps_per_batch": tm.get("batch"),
+                       "synthesis_and_step_fused": tm.get("fused")},
+            "accept_rate": float(acc.mean()), "timed_seconds": loop,
+            "wall_seconds_incl_engine_setup_and_bed_transfers": dt, "rate_incl_engine_setup_and_bed_transfers": n_chains * n_steps / dt,
+            # same numerator as the headline line (the chain state a step must move), over the whole batch loop: the
+            # white-noise planes that gsm_draw_pcg64 hands to the chain kernel through HBM are traffic of this mode's own making
+            "roofline": {"bound": "hbm", "achieved": alg / loop / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / loop / 8e12, "traffic": None,
+                         "kernel": "pcg64_draw_kernel + chain_strip_kernel<NOISE> (gsm_run_noise), one after the other",
+                         "algorithmic_bytes_per_chain_step": alg / (n_chains * n_steps)},
+            "note": "value = the draw / synthesis / step batches with the chain state resident in HBM (synchronised before and after); "
+                    "host-drawn replay mode on the same box: 25-41 k chain-steps/s with 15 draw workers (scripts/replay_batch_bench.py)"}
 
 
 def main():

@@ -675,7 +675,8 @@ def run_many_replay(chain, RF, initial_beds, rf_states, chain_states, n_iter, ch
     return out, rf_states, chain_states
 
 
-def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, batch=None, device=None, progress=False, fused=None):
+def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, batch=None, device=None, progress=False, fused=None,
+                   timing=None):
     """The 'pcg64' draw mode: run_many_replay with NO host draws.  Chain c's two NumPy generators (rf_states[c], chain_states[c]:
     `Generator.bit_generator.state` dicts of PCG64 generators) are advanced ON THE DEVICE, bit for bit as NumPy advances them
     (gsm_draw_pcg64: PCG64, the 32-bit half cache of integers(), Lemire's bounded integers, uniform, the ziggurat normal), in
@@ -685,7 +686,9 @@ def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, bat
     generator states are identical; accept masks are identical unless an accept uniform falls within ~1e-12 of its threshold;
     beds and losses agree to the accuracy of the device's inverse DFT against pocketfft (tests/test_gpu_pcg64.py).
     fused (default: whenever the block table goes to the strip kernels): synthesis and step in ONE kernel per batch
-    (gsm_run_noise: the field never leaves the CU) -- bit-identical to the two calls."""
+    (gsm_run_noise: the field never leaves the CU) -- bit-identical to the two calls.
+    timing: a dict that receives 'loop_seconds' -- the draw / synthesis / step batches alone, chain state resident in HBM
+    (synchronised before and after) -- and 'fused'."""
     import ctypes as C
     import torch
     from .engine import GsmEngine, _ptr
@@ -713,8 +716,11 @@ def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, bat
             fused = eng.strip_active() and os.environ.get("GSM_PCG64_FUSED", "1") != "0"
         elif fused and not eng.strip_active():
             raise NotImplementedError("run_many_pcg64(fused=True): this block table does not go to the strip kernels")
-        if batch is None:      # two sets of three noise planes + the fields of a batch: at most ~16 GiB
-            batch = int(max(1, min(256, (16 << 30) // (7 * n_chains * stride * 8))))
+        if batch is None:
+            # Two sets of three noise planes (+ the fields of a batch without the fused kernel): at most ~48 GiB of the 288.  Long
+            # batches matter: the draw kernel and the chain kernel are persistent workgroups that fill the chip one after the
+            # other (4.2 M chain-steps/s at 46 steps per batch, 4.8 M at 128; 1024 chains at 256 x 256, state resident).
+            batch = int(max(1, min(256, (48 << 30) // ((6 if fused else 7) * n_chains * stride * 8))))
         batch = max(1, min(int(batch), max(n_steps, 1)))
         n_al = max(n_steps, 1)
         loss = torch.empty((n_chains, n_al), dtype=torch.float64, device=dev)
@@ -743,6 +749,7 @@ def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, bat
                 ev_drawn[k & 1].record(s_draw)
             return d
 
+        torch.cuda.synchronize(dev)
         t0 = time.time()
         done = 0
         nxt = draw(0) if sizes else None
@@ -779,6 +786,10 @@ def run_many_pcg64(chain, RF, initial_beds, rf_states, chain_states, n_iter, bat
                       file=sys.stdout, flush=True)
         cur.wait_stream(s_draw); cur.wait_stream(s_step)
         torch.cuda.synchronize(dev)
+        if timing is not None:
+            timing['loop_seconds'] = time.time() - t0
+            timing['fused'] = bool(fused)
+            timing['batch'] = batch
         si = si_all[:, :n_steps].cpu().numpy()
         blocks[:, :, 0:2] = ce_all[:, :n_steps].cpu().numpy()
         blocks[:, :, 2] = eng.bh[si]

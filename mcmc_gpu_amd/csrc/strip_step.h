@@ -231,21 +231,22 @@ __device__ __forceinline__ void load_state(const Lane& L_in, const int n, const 
     }
   }
 #pragma unroll
-  for (int R = 1; R <= kNR; ++R) {
-    ve[R - 1] = 0.0;
-    if (R <= n) {
-      uint32_t off, soff;
-      row_offsets<INTERIOR>(L, R, W, (uint32_t)sizeof(TS), off, soff);
-      ve[R - 1] = RowIO<TS>::load(r_en, (row_own(L, R) && colown) ? off : kOOB, soff);
-    }
-  }
-#pragma unroll
   for (int R = 1; R <= kNA; ++R) {
     a2[R - 1] = make_double2(0.0, 0.0);
     if (R <= n) {
       uint32_t off, soff;
       row_offsets<INTERIOR>(L, R, W, 16u, off, soff);
       a2[R - 1] = ld_f64x2(r_st, (row_own(L, R) && colown) ? off : kOOB, soff);
+    }
+  }
+  // the carried energies last: they are only summed, at the end of phase A (loads return in the order they were issued)
+#pragma unroll
+  for (int R = 1; R <= kNR; ++R) {
+    ve[R - 1] = 0.0;
+    if (R <= n) {
+      uint32_t off, soff;
+      row_offsets<INTERIOR>(L, R, W, (uint32_t)sizeof(TS), off, soff);
+      ve[R - 1] = RowIO<TS>::load(r_en, (row_own(L, R) && colown) ? off : kOOB, soff);
     }
   }
 }
@@ -262,11 +263,6 @@ __device__ __forceinline__ void phase_a(const Lane& L_in, const int n, const int
   const int W = fresh_s(W_in);
   const WriteMasks wm = write_masks(L);
   const bool colown = has(L, kFColOwn);
-  acc_old = 0.0;
-#pragma unroll
-  for (int R = 1; R <= kNR; ++R) if (R <= n) acc_old += ve[R - 1];
-  asm volatile("" : "+v"(acc_old));
-  __builtin_amdgcn_sched_barrier(0);
   guard = false;
   upd_bits = 0u;
   const int ts = bw + 2;
@@ -295,6 +291,10 @@ __device__ __forceinline__ void phase_a(const Lane& L_in, const int n, const int
       if (cell_written<INTERIOR>(L, wm, jj)) tile[L.tidx + jj * ts] = v;
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
+  acc_old = 0.0;
+#pragma unroll
+  for (int R = 1; R <= kNR; ++R) if (R <= n) acc_old += ve[R - 1];
 }
 
 template <int CTRL>

@@ -16,11 +16,13 @@ if __name__ == "__main__":
     st = [np.random.default_rng(seed=900 + i).bit_generator.state for i in range(a.chains)]
     MCMC_gpu.run_many_pcg64(ch, rf, beds[:8], st[:8], st[:8], 9)                    # warm-up
     t0 = time.time()
-    out, _, _ = MCMC_gpu.run_many_pcg64(ch, rf, beds, st, st, a.iters, batch=a.batch or None)
+    tm = {}
+    out, _, _ = MCMC_gpu.run_many_pcg64(ch, rf, beds, st, st, a.iters, batch=a.batch or None, timing=tm)
     dt = time.time() - t0
     acc = np.mean([o[4][1:].mean() for o in out])
     print(f"pcg64 mode: {a.chains} chains x {a.iters - 1} steps at {a.grid}^2: {dt:.2f} s = {a.chains * (a.iters - 1) / dt / 1e6:.3f} M chain-steps/s "
-          f"(incl. engine setup and result download), accept {acc:.3f}")
+          f"(incl. engine setup and result download); state resident in HBM: {tm['loop_seconds']:.3f} s = "
+          f"{a.chains * (a.iters - 1) / tm['loop_seconds'] / 1e6:.3f} M chain-steps/s (fused {tm['fused']}, batch {tm['batch']}), accept {acc:.3f}")
     if a.replay:
         n = min(a.chains, 64)
         t0 = time.time()
