@@ -480,6 +480,11 @@ class chain_crf_gpu:
                 import ctypes as C
                 import torch
                 from .engine import GsmEngine, _ptr
+                if RF.rng is self.rng or RF.rng.bit_generator is self.rng.bit_generator:
+                    # the device advances the two streams independently; one shared generator interleaves its draws between the
+                    # proposal and the chain (set_random_generator's docstring) -- only the host-drawn replay mode follows that
+                    raise ValueError("'pcg64' mode needs separate generators for the RandField and the chain (a shared generator "
+                                     "interleaves the two draw sequences: use the 'replay' mode for that)")
                 p64 = eng.rf_struct(RF)
                 d_rf = torch.as_tensor(GsmEngine.pack_pcg64_states([RF.rng]).view(np.int64)).to(eng.dev)
                 d_ch = torch.as_tensor(GsmEngine.pack_pcg64_states([self.rng]).view(np.int64)).to(eng.dev)

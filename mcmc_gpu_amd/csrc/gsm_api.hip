@@ -903,11 +903,15 @@ static int sgs_fill(gsm_handle h, SgsArgs& a, double* grids, const double* zcond
   if (!(radius > 0.0)) return fail(h, GSM_E_ARG, std::string(who) + ": radius must be > 0");
   if (lag_mi < 0 || lag_mj < 0) return fail(h, GSM_E_ARG, std::string(who) + ": lag table extents must be >= 0");
   if (max_cells < 1 || max_cells > 1024) return fail(h, GSM_E_ARG, std::string(who) + ": max_cells must be in [1, 1024]");
-  if (h->H < 2 || h->W < 2 || h->H > 65535 || h->W > 65535) return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": grid sides must be in [2, 65535]");
+  // cells travel packed as (row << 16 | col) in an int32 and are unpacked with an arithmetic shift: rows up to 32767
+  if (h->H < 2 || h->W < 2 || h->H > 32767 || h->W > 32767) return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": grid sides must be in [2, 32767]");
   // scratch: per (chain, slot) 48 x (value, weight) and a header; then ranks [n][1024] i32, rank_ok [n] i32
   max_cells = (max_cells + 31) & ~31;                        // record stride: whole 32-cell chunks (sgs_sequence_kernel stages them by LDS-DMA)
   const size_t n = (size_t)h->n_chains, cells_cap = n * (size_t)max_cells;
   if (h->sgs_rec_cells < cells_cap) {
+    // a captured batch (gsm_sgs_iterate's hipGraph) holds the old scratch pointers: it must not be replayed
+    if (h->sgs_graph_exec) { hipGraphExecDestroy(h->sgs_graph_exec); h->sgs_graph_exec = nullptr; }
+    h->sgs_graph_key.clear();
     if (h->d_sgs_rec) { hipFree(h->d_sgs_rec); h->d_sgs_rec = nullptr; h->sgs_rec_cells = 0; }
     const size_t bytes = n * 1024 * 4 + n * 4 + 64 + cells_cap * (sizeof(SgsCellHdr) + 48 * sizeof(double2));
     hipError_t e = hipMalloc(&h->d_sgs_rec, bytes);
@@ -1003,6 +1007,7 @@ extern "C" int gsm_sgs_draw_philox(gsm_handle h, const uint64_t* seeds, int64_t 
   if (n_iters < 1 || n_iters > 65535 || iter0 < 0) return fail(h, GSM_E_ARG, "gsm_sgs_draw_philox: n_iters must be in [1, 65535], iter0 >= 0");
   if (min_x < 1 || max_x <= min_x || min_y < 1 || max_y <= min_y) return fail(h, GSM_E_ARG, "gsm_sgs_draw_philox: block size ranges must be 1 <= min < max");
   if (max_cells < (max_x - 1) * (max_y - 1) || max_cells > 1024) return fail(h, GSM_E_ARG, "gsm_sgs_draw_philox: max_cells must hold the largest block and be <= 1024");
+  if ((int64_t)n_iters * h->n_chains * max_cells >= (1LL << 31)) return fail(h, GSM_E_ARG, "gsm_sgs_draw_philox: n_iters * n_chains * max_cells must stay below 2^31 (32-bit cell offsets)");
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->d_mathtab) {
     double tab[kMathTabDoubles];
@@ -1029,7 +1034,8 @@ extern "C" int gsm_sgs_draw_pcg64(gsm_handle h, uint64_t* chain_state, int32_t n
   if (n_iters < 1 || n_iters > 65535) return fail(h, GSM_E_ARG, "gsm_sgs_draw_pcg64: n_iters must be in [1, 65535]");
   if (min_x < 1 || max_x <= min_x || min_y < 1 || max_y <= min_y) return fail(h, GSM_E_ARG, "gsm_sgs_draw_pcg64: block size ranges must be 1 <= min < max");
   if (max_cells < (max_x - 1) * (max_y - 1) || max_cells > 1024) return fail(h, GSM_E_ARG, "gsm_sgs_draw_pcg64: max_cells must hold the largest block and be <= 1024");
-  if (h->H > 65535 || h->W > 65535) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_draw_pcg64: grid sides up to 65535");
+  if (h->H > 32767 || h->W > 32767) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_draw_pcg64: grid sides up to 32767 (cells are packed as row << 16 | col)");
+  if ((int64_t)n_iters * h->n_chains * max_cells >= (1LL << 31)) return fail(h, GSM_E_ARG, "gsm_sgs_draw_pcg64: n_iters * n_chains * max_cells must stay below 2^31 (32-bit cell offsets)");
   HIPCHK(h, hipSetDevice(h->device));
   { int rc = ensure_pcg_tables(h); if (rc) return rc; }
   SgsDrawArgs a{};
@@ -1049,6 +1055,8 @@ extern "C" int gsm_sgs_loss(gsm_handle h, const double* beds, const double* tren
   HIPCHK(h, hipSetDevice(h->device));
   const size_t need = (size_t)h->n_chains * sgs_loss_parts(h->S);
   if (h->sgs_part_cap < need) {
+    if (h->sgs_graph_exec) { hipGraphExecDestroy(h->sgs_graph_exec); h->sgs_graph_exec = nullptr; }     // captured with the old scratch
+    h->sgs_graph_key.clear();
     if (h->d_sgs_part_sum) { hipFree(h->d_sgs_part_sum); hipFree(h->d_sgs_part_bad); h->d_sgs_part_sum = nullptr; h->d_sgs_part_bad = nullptr; h->sgs_part_cap = 0; }
     HIPCHK(h, hipMalloc(&h->d_sgs_part_sum, need * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->d_sgs_part_bad, need * sizeof(int32_t)));

@@ -512,7 +512,7 @@ __global__ __launch_bounds__(64) void sgs_sequence_kernel(const SgsArgs a) {
 }
 
 hipError_t launch_sgs_blocks(const SgsArgs& a, int launch_cells, hipStream_t st) {
-  if (a.hw < 1 || a.num_points < 8 || a.num_points > kSgsMaxPts || a.H < 2 || a.W < 2 || a.H > 65535 || a.W > 65535) return hipErrorInvalidValue;
+  if (a.hw < 1 || a.num_points < 8 || a.num_points > kSgsMaxPts || a.H < 2 || a.W < 2 || a.H > 32767 || a.W > 32767) return hipErrorInvalidValue;
   hipLaunchKernelGGL(sgs_rank_kernel, dim3(a.n_chains), dim3(256), 0, st, a);
   if (launch_cells > 0) hipLaunchKernelGGL(sgs_weights_kernel, dim3(launch_cells, a.n_chains), dim3(64), 0, st, a);
   hipLaunchKernelGGL(sgs_sequence_kernel, dim3(a.n_chains), dim3(64), 0, st, a);

@@ -67,6 +67,7 @@ def _save_segment(seed_folder, result, n_iter, prev, rf_state, chain_state, phil
     with open(seed_folder / 'RNGState_philox.txt', 'w') as fh:
         json.dump(philox_state, fh)
     cumulative = 0
+    label_count = 0
     if prev is not None:
         p = prev['results']
         loss_mc = np.concatenate([p['loss_mc'], loss_mc])
@@ -76,8 +77,9 @@ def _save_segment(seed_folder, result, n_iter, prev, rf_state, chain_state, phil
         resampled = p['resampled_times'] + resampled
         blocks = np.vstack([p['blocks_used'], blocks])
         cumulative = prev['cumulative']
+        label_count = prev.get('label_count', cumulative)
     cumulative += n_iter
-    label = f'{cumulative // 1000}k'
+    label = f'{(label_count + n_iter) // 1000}k'
     np.save(seed_folder / f'bed_{label}.npy', beds)
     np.savez_compressed(seed_folder / f'results_{label}.npz', loss_mc=loss_mc, loss_data=loss_data, loss=loss,
                         steps=steps, resampled_times=resampled, blocks_used=blocks)
@@ -288,7 +290,8 @@ def _msc_load_previous(seed_folder):
         return None
     k = int(beds[0].stem.split('_')[1].replace('k', ''))
     prev = {key: np.loadtxt(seed_folder / f'{key}_{k}k.txt') for key in _MSC_FILES}
-    return dict(cumulative=int(np.atleast_1d(prev['loss']).shape[0]), bed=np.loadtxt(beds[0]), results=prev,
+    # label_count: what the reference continues its FILE LABELS from (k * 1000, :322-383); cumulative: the exact count
+    return dict(cumulative=int(np.atleast_1d(prev['loss']).shape[0]), label_count=1000 * k, bed=np.loadtxt(beds[0]), results=prev,
                 delete=[seed_folder / f'bed_{k}k.txt'] + [seed_folder / f'{key}_{k}k.txt' for key in _MSC_FILES])
 
 
@@ -297,6 +300,7 @@ def _msc_save(seed_folder, result, n_iter, prev):
     seed_folder.mkdir(parents=True, exist_ok=True)
     beds, loss_mc, loss_data, loss, steps, resampled, blocks = result[:7]
     cumulative = 0
+    label_count = 0
     if prev is not None:
         p = prev['results']
         loss_mc = np.concatenate([np.atleast_1d(p['loss_mc']), loss_mc])
@@ -306,8 +310,9 @@ def _msc_save(seed_folder, result, n_iter, prev):
         resampled = p['resampled_times'] + resampled
         blocks = np.vstack([p['blocks_used'], blocks])
         cumulative = prev['cumulative']
+        label_count = prev.get('label_count', cumulative)
     cumulative += n_iter
-    label = f'{cumulative // 1000}k'
+    label = f'{(label_count + n_iter) // 1000}k'
     for key, arr in zip(('bed',) + _MSC_FILES, (beds, loss_mc, loss_data, loss, steps, resampled, blocks)):
         np.savetxt(seed_folder / f'{key}_{label}.txt', arr)
     if prev is not None:

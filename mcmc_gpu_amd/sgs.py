@@ -409,7 +409,9 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
         loss_prev, _ = loss_of(cur)
         # no transformer: only the block and its one-cell halo change per iteration -> carried squared residuals, windowed loss,
         # and loss / guard / acceptance test / commit in ONE launch (gsm_sgs_finish); the reference recomputes the whole map
-        windowed = nst is None and os.environ.get('GSM_SGS_WINDOWED', '1') != '0'
+        # (gsm_sgs_finish keeps block + halo in LDS: 36 x 36 cells; a longer, thinner block takes the whole-map path)
+        windowed = (nst is None and os.environ.get('GSM_SGS_WINDOWED', '1') != '0' and
+                    (int(chain.block_max_x) + 1) * (int(chain.block_max_y) + 1) <= 1296)
         if windowed:
             d_energy = torch.empty((n, H, W), dtype=torch.float64, device=dev)
             d_state = torch.empty((n, 4), dtype=torch.float64, device=dev)

@@ -139,6 +139,7 @@ def driver_chain(prob, trend, nst, seed, vario_param=None, sgs_param=None, block
 
 # ---- golden F12: the reference's module-level MCMC.sgs with ordinary and simple kriging (oracle/make_fixtures_r3b.py) -------------
 GOLD12 = ROOT / "tests" / "golden" / "f12_sgs_function_ok_sk.npz"
+GOLD13 = GOLD12.parent / "f13_sgs_driver_deep64.npz"
 F12_CASES = ("ok", "sk", "skm")
 
 

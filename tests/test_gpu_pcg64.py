@@ -192,3 +192,15 @@ def test_small_scale_device_draws_equal_numpy():
             assert u[j, c] == uu
         assert states[c] == gens[c].bit_generator.state
     eng.close()
+
+
+def test_pcg64_mode_refuses_a_generator_shared_by_randfield_and_chain():
+    """The reference lets one Generator serve both the RandField and the chain (draws interleave); the device advances two
+    independent streams, so 'pcg64' mode must refuse that set-up instead of silently diverging (replay mode handles it)."""
+    from mcmc_gpu_amd import synthetic
+    prob, ch, rf = synthetic.template(64)
+    c, r = _rehydrate(ch, rf, 7, prob["bed"].copy())
+    r.rng = c.rng
+    c.set_rng_mode('pcg64')
+    with pytest.raises(ValueError, match="separate generators"):
+        c.run(5, r, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None)

@@ -87,9 +87,46 @@ def test_chain_sgs_gpu_equals_reference_fixture(tag):
     assert out[4].sum() >= 2
 
 
-def test_small_scale_driver_runs_config0_literally(tmp_path):
-    """BASELINE configs[0]: smallScaleChain, 64x64 grid, 4 chains, through the smallScaleChain_mp counterpart; all four
-    chains in one handle == each chain alone through msc_run_wrapper (text files included), and a second segment resumes."""
+def test_small_scale_driver_at_the_reference_drivers_parameters(tmp_path):
+    """BASELINE configs[0] literally: smallScaleChain, 64x64 grid, 4 chains, at the parameters of the reference's own driver
+    (smallScaleChain_multiprocessing.py:470-560 through synthetic.sgs_template: set_sgs_param(48, 30e3) at 500 m = 60-cell search
+    half-width, blocks 5-20, Matern, QuantileTransformer(1000), trend, sigma_mc 5) through smallScaleChain_mp / msc_run_wrapper
+    (:211-399) with their text checkpoints: all four chains in one handle == each chain alone, file for file; a second segment
+    resumes from the files; the device-drawn 'pcg64' mode writes the same files as the host-drawn replay mode."""
+    from copy import deepcopy
+    from mcmc_gpu_amd import driver, synthetic
+    prob, ch = synthetic.sgs_template(64)
+    assert ch.sgs_param[0] == 48 and ch.sgs_param[1] == 30e3 and ch.nst_trans is not None and ch.detrend_map
+    seeds = [901, 902, 903, 904]
+    beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(4)]
+    n_it = 1000
+    res = driver.smallScaleChain_mp(4, 3, ch, beds, seeds, 123456789, [n_it] * 4, output_path=str(tmp_path / "all"))
+    base = tmp_path / "all" / "LargeScaleChain" / "123456" / "SmallScaleChain"
+    keys = ("bed", "loss_mc", "loss_data", "loss", "steps", "resampled_times", "blocks_used")
+    assert sorted(p.name for p in (base / "902").iterdir()) == sorted(f"{k}_1k.txt" for k in keys)
+    cp = deepcopy(ch.__dict__); cp["rng_seed"] = 902; cp["initial_bed"] = beds[1]
+    alone = driver.msc_run_wrapper(cp, dict(n_iter=n_it, only_save_last_bed=True, info_per_iter=10, plot=False, progress_bar=False,
+                                            chain_id=1, tqdm_position=3, ssc_seed=902, lsc_seed=123456789,
+                                            output_path=str(tmp_path / "alone")))
+    for a, b in zip(res[1], alone):
+        assert np.array_equal(a, b, equal_nan=True)                   # same device arithmetic: bit-equal
+    for k in keys:
+        assert np.array_equal(np.loadtxt(base / "902" / f"{k}_1k.txt"), np.loadtxt(tmp_path / "alone" / "902" / f"{k}_1k.txt")), k
+    assert 0.005 < np.mean([r[4].mean() for r in res]) < 0.5         # sigma_mc 5 accepts a few per cent on the synthetic problem
+    # the same chains with the generator advanced on the device: same files
+    res_p = driver.smallScaleChain_mp(4, 3, ch, beds, seeds, 123456789, [n_it] * 4, output_path=str(tmp_path / "pcg"), mode='pcg64')
+    for a, b in zip(res, res_p):
+        assert np.array_equal(a[4], b[4]) and np.array_equal(a[6], b[6], equal_nan=True) and np.array_equal(a[0], b[0])
+    # second segment resumes from the text files
+    driver.smallScaleChain_mp(4, 3, ch, beds, seeds, 123456789, [n_it] * 4, output_path=str(tmp_path / "all"))
+    assert sorted(p.name for p in (base / "903").iterdir()) == sorted(f"{k}_2k.txt" for k in keys)
+    assert np.loadtxt(base / "903" / "loss_2k.txt").shape == (2000,)
+
+
+def test_small_scale_driver_light_configuration(tmp_path):
+    """The LIGHT test configuration of rounds 1-2 (16 neighbours within 4 km, blocks 3-8, no transformer) through the
+    smallScaleChain_mp counterpart: all four chains in one handle == each chain alone through msc_run_wrapper (text files
+    included), and a second segment resumes.  (The reference driver's own parameters: the test above.)"""
     from copy import deepcopy
     from mcmc_gpu_amd import driver, sgs
     prob = sc.problem(64)
@@ -521,3 +558,37 @@ def test_transformer_of_another_class_runs_on_the_host_in_every_draw_mode(mode):
     np.testing.assert_allclose(a[3], b[3], rtol=1e-9)
     np.testing.assert_allclose(a[0], b[0], rtol=0, atol=1e-7)
     assert 0.05 < a[4].mean() < 0.95
+
+
+def test_checkpoint_labels_follow_the_reference_when_n_iter_is_not_a_multiple_of_1000(tmp_path):
+    """Two 1500-iteration segments: the reference restarts its label arithmetic from k * 1000 (smallScaleChain_multiprocessing.py:
+    322-383), so the files are *_1k.txt, then *_2k.txt ((1000 + 1500) // 1000) -- not 3k -- while the stored records hold all 3000
+    iterations (and a Philox-mode resume continues its counters at 3000)."""
+    from mcmc_gpu_amd import driver, synthetic
+    prob, ch = synthetic.sgs_template(64, transform=False, light=True)
+    seeds, beds = [911], [prob["bed"]]
+    for _ in range(2):
+        driver.smallScaleChain_mp(1, 1, ch, beds, seeds, 123456789, [1500], output_path=str(tmp_path))
+    folder = tmp_path / "LargeScaleChain" / "123456" / "SmallScaleChain" / "911"
+    assert sorted(p.name for p in folder.iterdir()) == sorted(
+        f"{k}_2k.txt" for k in ("bed", "loss_mc", "loss_data", "loss", "steps", "resampled_times", "blocks_used"))
+    assert np.loadtxt(folder / "loss_2k.txt").shape == (3000,)
+    assert driver._msc_load_previous(folder)["cumulative"] == 3000
+
+
+def test_elongated_blocks_without_a_transformer_take_the_whole_map_path(monkeypatch):
+    """Blocks up to 3 x 59 cells (legal: <= 1024 cells) exceed the 36 x 36 halo tile of the windowed iteration end
+    (gsm_sgs_finish), which aborted such chains with error flag 1: the chain now takes the whole-map loss / decide / commit path
+    for such a block table -- the same results as with the windowed path switched off by hand."""
+    from mcmc_gpu_amd import synthetic
+    outs = []
+    for windowed in ("1", "0"):
+        monkeypatch.setenv("GSM_SGS_WINDOWED", windowed)
+        prob, ch = synthetic.sgs_template(64, transform=False, light=True)
+        ch.set_block_sizes(2, 4, 30, 60)
+        ch.set_random_generator(rng_seed=77)
+        outs.append(ch.run(40, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None))
+    a, b = outs
+    assert np.isfinite(a[3]).all() and np.nanmax(a[6][1:, 2:4]) > 36          # a block longer than the halo tile was drawn
+    for k in (0, 3, 4, 5):
+        assert np.array_equal(a[k], b[k]), k

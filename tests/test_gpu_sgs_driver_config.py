@@ -43,6 +43,27 @@ def test_chain_sgs_gpu_equals_reference_at_driver_config(tag, mode):
         assert np.abs(out[0] - g["a_native_bed"]).max() < 2.0
 
 
+@pytest.mark.parametrize("mode", ["replay", "pcg64"])
+def test_chain_sgs_gpu_equals_reference_over_a_deep_driver_run(mode):
+    """Golden F13 (oracle/make_fixtures_r4.py): the UNMODIFIED reference at the driver's parameters on the tie-free geometry with
+    sigma_mc = 30 -- 160 iterations, 68 of them accepted, so the values the device simulates (Gauss-Jordan where the reference calls
+    lstsq) pass through the inverse transform and the commit and condition later iterations 68 times.  Index work identical (accept
+    mask, blocks, resampled counts, generator state); values to the tolerances of the F11 test, which hold over this depth too:
+    loss 1e-8 relative, bed 1e-6 m."""
+    from test_oracle_sgs_golden import f13_case
+    g, prob, trend, nst, sigma = f13_case()
+    ch = sc.driver_chain(prob, trend, nst, int(g["d_seed"]), None, None, None, sigma)
+    ch.set_rng_mode(mode)
+    out = ch.run(int(g["d_n_iter"]), only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None)
+    assert np.array_equal(out[6], g["d_blocks"]), "blocks"
+    assert np.array_equal(out[4], g["d_steps"]), "accept mask differs from the reference"
+    assert np.array_equal(out[5], g["d_resampled"]), "resampled counts"
+    assert ch.rng.bit_generator.state == json.loads(str(g["d_rng_state"]))
+    np.testing.assert_allclose(out[3], g["d_loss"], rtol=1e-8)
+    np.testing.assert_allclose(out[0], g["d_bed"], rtol=0, atol=1e-6)
+    assert out[4].sum() >= 30
+
+
 def _one_iteration_inputs(ch, prob, rngs, cond_is_data):
     n = len(rngs)
     wins = np.empty((n, 4), np.int32); offs = np.zeros(n + 1, np.int32)

@@ -137,6 +137,41 @@ def test_sgs_oracle_reproduces_driver_config_fixture(tag):
         assert tr[:, 2].min() >= 1                         # the widened search found something for every cell
 
 
+def f13_case():
+    """Golden F13 (oracle/make_fixtures_r4.py): the driver configuration on the tie-free geometry, sigma_mc 30, 160 iterations."""
+    g = np.load(sc.GOLD13, allow_pickle=False)
+    prob = sc.driver_problem(int(g["H"]), dy=float(g["tie_free_dy"]))
+    trend, nst = sc.driver_trend_and_transformer(sc.driver_problem(int(g["H"])))
+    assert hashlib.sha256(np.ascontiguousarray(trend).tobytes()).hexdigest() == str(g["trend_sha"]), "scipy's gaussian_filter differs here"
+    assert hashlib.sha256(np.ascontiguousarray(nst.quantiles_).tobytes()).hexdigest() == str(g["quantiles_sha"]), "sklearn's quantiles differ here"
+    return g, prob, trend, nst, float(g["sigma_mc"])
+
+
+def test_sgs_oracle_reproduces_deep_driver_fixture():
+    """F13: the UNMODIFIED reference at the driver's parameters (48 neighbours / 30 km, blocks 5-20, Matern, QuantileTransformer(1000),
+    trend) over 160 iterations with 68 accepted -- the accepted path (inverse transform, commit, the next iteration conditioning on
+    the committed values) is walked 68 times, against twice in F11's cases a / t."""
+    g, prob, trend, nst, sigma = f13_case()
+    cfg = sc.driver_cfg(prob, trend, nst, None, None, None, sigma)
+    rng = np.random.default_rng(seed=int(g["d_seed"]))
+    trace = []
+    so.STABLE_TIES, so.TIE_LOG = False, []
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = so.run_chain_sgs(cfg, prob["bed"], int(g["d_n_iter"]), rng, trace=trace)
+        tied = len(so.TIE_LOG)
+    finally:
+        so.STABLE_TIES, so.TIE_LOG = False, None
+    assert tied == 0 == int(g["d_tied_cuts"])
+    for k, name in ((0, "bed"), (3, "loss"), (4, "steps"), (5, "resampled"), (6, "blocks")):
+        assert np.array_equal(out[k], g[f"d_{name}"], equal_nan=True), name
+    assert rng.bit_generator.state == json.loads(str(g["d_rng_state"]))
+    assert int(out[4].sum()) >= 30
+    assert hashlib.sha256(np.ascontiguousarray(np.array(trace)).tobytes()).hexdigest() == str(g["d_trace_sha"])
+
+
 @pytest.mark.parametrize("tag", ["ok", "sk", "skm"])
 def test_sgs_function_oracle_reproduces_reference_fixture_ok_and_sk(tag):
     """Golden F12 (oracle/make_fixtures_r3b.py): the reference's module-level MCMC.sgs with ktype 'ok' and 'sk' (_krige.py:5-81)
