@@ -349,7 +349,8 @@ def test_small_scale_driver_philox_mode_segments(tmp_path):
     two = driver.smallScaleChain_mp(3, 1, ch, beds, seeds, 5, [1500] * 3, output_path=str(tmp_path / "two15"), mode='philox')
     for c in range(3):
         assert np.array_equal(one[c][4][1500:], two[c][4]) and np.array_equal(one[c][6][1500:], two[c][6])
-    assert np.loadtxt(tmp_path / "two15" / "LargeScaleChain" / "5" / "SmallScaleChain" / "811" / "steps_3k.txt").shape == (3000,)
+    # file label as the reference computes it ((1000 + 1500) // 1000 = 2: its label arithmetic restarts from k * 1000); the record holds all 3000
+    assert np.loadtxt(tmp_path / "two15" / "LargeScaleChain" / "5" / "SmallScaleChain" / "811" / "steps_2k.txt").shape == (3000,)
 
 
 def test_small_scale_driver_starts_its_own_ranks(tmp_path, monkeypatch):
@@ -577,18 +578,18 @@ def test_checkpoint_labels_follow_the_reference_when_n_iter_is_not_a_multiple_of
 
 
 def test_elongated_blocks_without_a_transformer_take_the_whole_map_path(monkeypatch):
-    """Blocks up to 3 x 59 cells (legal: <= 1024 cells) exceed the 36 x 36 halo tile of the windowed iteration end
-    (gsm_sgs_finish), which aborted such chains with error flag 1: the chain now takes the whole-map loss / decide / commit path
-    for such a block table -- the same results as with the windowed path switched off by hand."""
+    """A block table up to 8 x 128 cells is legal (<= 1024 cells) but its block + halo, 10 x 130 = 1300 cells, exceeds the 1296-cell
+    LDS tile of the windowed iteration end (gsm_sgs_finish), which used to abort such chains with error flag 1: the chain now takes
+    the whole-map loss / decide / commit path for such a table -- the same results as with the windowed path switched off by hand."""
     from mcmc_gpu_amd import synthetic
     outs = []
     for windowed in ("1", "0"):
         monkeypatch.setenv("GSM_SGS_WINDOWED", windowed)
-        prob, ch = synthetic.sgs_template(64, transform=False, light=True)
-        ch.set_block_sizes(2, 4, 30, 60)
+        prob, ch = synthetic.sgs_template(160, transform=False, light=True)
+        ch.set_block_sizes(2, 9, 100, 129)
         ch.set_random_generator(rng_seed=77)
-        outs.append(ch.run(40, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None))
+        outs.append(ch.run(25, only_save_last_bed=True, info_per_iter=10 ** 9, plot=False, progress_bar=None))
     a, b = outs
-    assert np.isfinite(a[3]).all() and np.nanmax(a[6][1:, 2:4]) > 36          # a block longer than the halo tile was drawn
+    assert np.isfinite(a[3]).all() and np.nanmax(a[6][1:, 2:4]) > 100          # long blocks were drawn
     for k in (0, 3, 4, 5):
         assert np.array_equal(a[k], b[k]), k
