@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak
 
 
-def pmc_traffic(H, n_chains, state):
+def pmc_traffic(H, n_chains, state, kernel="chain_fused_kernel"):
     """HBM-side bytes per chain-step of the fused chain kernel from the COMMITTED rocprofv3 PMC passes
     (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of scripts/pmc_fused.py,
     calibrated on a stream copy of known size, MI355X_MICROARCH.md HBM section), plus the SQ counters of the same
@@ -53,7 +53,7 @@ def pmc_traffic(H, n_chains, state):
     (None, None, None) when no measurement matches this config."""
     try:
         d = json.load(open(ROOT / "profiles" / "pmc_traffic.json"))
-        if (d["grid"], d["chains"], d.get("state", "f64")) == (H, n_chains, state):
+        if (d["grid"], d["chains"], d.get("state", "f64")) == (H, n_chains, state) and kernel in d.get("kernel", "chain_fused_kernel"):
             sq = {k: d[k] for k in ("valu_busy_frac_per_simd", "mfma_busy_frac_per_simd",
                                     "valu_wave_instructions_per_chain_step", "mfma_instructions_per_chain_step",
                                     "salu_instructions_per_chain_step") if k in d}
@@ -243,6 +243,7 @@ def measure(args, H, n_local, generator, state, inner, batch, steps, warmup, ran
     torch.cuda.synchronize(dev)
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     fused = bool(eng.last_run_fused())
+    strip = bool(eng.strip_active())          # chain_strip_kernel (two chains per CU) or chain_fused_kernel (one)
     eng.close()
     del eng
     if rank != 0:
@@ -268,10 +269,11 @@ def measure(args, H, n_local, generator, state, inner, batch, steps, warmup, ran
                 "algorithmic_flops_per_chain_step": flops_total / (n_local * n_timed), "flops_per_launch": flops_per_launch,
                 "step_kernel_ms": step_ms, "propose_kernel_ms": prop_ms, "launches": n_prop_l}
     else:
-        dom = "chain_fused_kernel" if fused else ("step_kernel" if t_step >= t_prop else "propose_kernel")
+        dom = (("chain_strip_kernel" if strip else "chain_fused_kernel") if fused else
+               ("step_kernel" if t_step >= t_prop else "propose_kernel"))
         dom_ms = prop_ms if dom == "propose_kernel" else step_ms
         achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        per_step, sq, src = pmc_traffic(H, n_local, state) if fused else (None, None, None)
+        per_step, sq, src = pmc_traffic(H, n_local, state, dom) if fused else (None, None, None)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": per_step * n_local * steps_per_launch if per_step else None,
                 "kernel": dom, "algorithmic_bytes_per_chain_step": bytes_total / (n_local * n_timed),

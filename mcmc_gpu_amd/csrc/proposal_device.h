@@ -276,6 +276,69 @@ __device__ __forceinline__ void dft_stage1(const int w, const int lane, const Pr
   const int l15 = lane & 15, l4 = lane >> 4;
   const int n_mt = g.M1 >> 4, n_nt = NR >> 4;
   const int n_t1 = n_mt * n_nt;
+  if constexpr (TABMODE == 2) {
+    // Two units at a time: per K step the eight operands of both are requested together, then four independent MFMAs follow --
+    // one exposed LDS round trip per four MFMAs instead of per two (a lone unit, the odd one out, runs two K steps per turn).
+    struct Unit { int ao; uint32_t m8, d8; const double* Ac; const double* As; bool on; };
+    const uint32_t n8 = 8u * (uint32_t)g.bh;
+    auto setup = [&](const int j) {
+      Unit x{0, 0u, 0u, Pr, Mi, false};
+      const int u = w + j * NW, t = u >> 1;
+      x.on = (j < UPW) && (t < n_t1) && !(a.dbg & 2);
+      if (x.on) {
+        const int nt = tile_div(t, g.q_mt), mt = t - nt * n_mt;
+        x.ao = l4 * SX + 16 * mt + l15;
+        x.Ac = (u & 1) ? Pi : Pr; x.As = (u & 1) ? Mr : Mi;
+        const uint32_t yy = mod_magic((uint32_t)(16 * nt + l15), (uint32_t)g.bh, sc.m_bh);
+        x.m8 = 8u * mod_magic((uint32_t)l4 * yy, (uint32_t)g.bh, sc.m_bh);       // byte index of (k, y) = 8 * ((k * y) mod bh)
+        x.d8 = 8u * mod_magic(4u * yy, (uint32_t)g.bh, sc.m_bh);                 // ... stepping k by 4
+      }
+      return x;
+    };
+    auto fetch = [&](Unit& x, const int k0, double& a1, double& a2, double& b1, double& b2) {
+      const char* tb = (const char*)tabA + x.m8;
+      const int o = x.ao + k0 * SX;
+      a1 = x.Ac[o]; a2 = x.As[o]; b1 = *(const double*)tb; b2 = *(const double*)(tb + 8 * kT1S);
+      x.m8 += x.d8;
+      x.m8 = min(x.m8, x.m8 - n8);            // unsigned: m8 - n8 wraps to a huge value when m8 < n8
+    };
+#pragma unroll
+    for (int j = 0; j < UPW; j += 2) {
+      Unit A = setup(j), B = setup(j + 1);
+      v4f64 cA = {0.0, 0.0, 0.0, 0.0}, sA = cA, cB = cA, sB = cA;
+      if (A.on && B.on) {
+        for (int k0 = 0; k0 < KR; k0 += 4) {
+          double a1, a2, b1, b2, a3, a4, b3, b4;
+          fetch(A, k0, a1, a2, b1, b2);
+          fetch(B, k0, a3, a4, b3, b4);
+          cA = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, cA, 0, 0, 0);
+          sA = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, sA, 0, 0, 0);
+          cB = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, cB, 0, 0, 0);
+          sB = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, b4, sB, 0, 0, 0);
+        }
+      } else if (A.on) {
+        int k0 = 0;
+        for (; k0 + 8 <= KR; k0 += 8) {
+          double a1, a2, b1, b2, a3, a4, b3, b4;
+          fetch(A, k0, a1, a2, b1, b2);
+          fetch(A, k0 + 4, a3, a4, b3, b4);
+          cA = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, cA, 0, 0, 0);
+          sA = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, sA, 0, 0, 0);
+          cA = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, cA, 0, 0, 0);
+          sA = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, b4, sA, 0, 0, 0);
+        }
+        if (k0 < KR) {
+          double a1, a2, b1, b2;
+          fetch(A, k0, a1, a2, b1, b2);
+          cA = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, cA, 0, 0, 0);
+          sA = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, sA, 0, 0, 0);
+        }
+      }
+      uc[j] = cA; us[j] = sA;
+      if (j + 1 < UPW) { uc[j + 1] = cB; us[j + 1] = sB; }
+    }
+    return;
+  }
   const double* __restrict__ FC = a.tables + sc.fy_off;      // [KR][NR]
   const double* __restrict__ FS = FC + KR * NR;
 #pragma unroll
@@ -290,37 +353,6 @@ __device__ __forceinline__ void dft_stage1(const int w, const int lane, const Pr
       const double* __restrict__ As = (u & 1) ? Mr : Mi;
       const double* fc_p = FC + l4 * NR + 16 * nt + l15;
       const double* fs_p = FS + l4 * NR + 16 * nt + l15;
-      // 1-D table: byte index of (k, y) = 8 * ((k * y) mod bh), stepping k by 4
-      const uint32_t n8 = 8u * (uint32_t)g.bh;
-      const uint32_t yy = mod_magic((uint32_t)(16 * nt + l15), (uint32_t)g.bh, sc.m_bh);
-      uint32_t m8 = 8u * mod_magic((uint32_t)l4 * yy, (uint32_t)g.bh, sc.m_bh);
-      const uint32_t d8 = 8u * mod_magic(4u * yy, (uint32_t)g.bh, sc.m_bh);
-      if (TABMODE == 2) {
-        // two K steps per iteration: eight operand reads in flight, then four MFMAs; KR / 4 may be odd: one step after the loop
-        auto operands = [&](const int k0, double& a1, double& a2, double& b1, double& b2) {
-          const char* tb = (const char*)tabA + m8;
-          const int o = ao + k0 * SX;
-          a1 = Ac[o]; a2 = As[o]; b1 = *(const double*)tb; b2 = *(const double*)(tb + 8 * kT1S);
-          m8 += d8;
-          m8 = min(m8, m8 - n8);            // unsigned: m8 - n8 wraps to a huge value when m8 < n8
-        };
-        int k0 = 0;
-        for (; k0 + 8 <= KR; k0 += 8) {
-          double a1, a2, b1, b2, a3, a4, b3, b4;
-          operands(k0, a1, a2, b1, b2);
-          operands(k0 + 4, a3, a4, b3, b4);
-          ac = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, ac, 0, 0, 0);
-          as = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, as, 0, 0, 0);
-          ac = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, ac, 0, 0, 0);
-          as = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, b4, as, 0, 0, 0);
-        }
-        if (k0 < KR) {
-          double a1, a2, b1, b2;
-          operands(k0, a1, a2, b1, b2);
-          ac = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, ac, 0, 0, 0);
-          as = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, as, 0, 0, 0);
-        }
-      } else {
 #pragma unroll 2
       for (int k0 = 0; k0 < KR; k0 += 4) {
         double bc, bs;
@@ -333,7 +365,6 @@ __device__ __forceinline__ void dft_stage1(const int w, const int lane, const Pr
         const int o = ao + k0 * SX;
         ac = __builtin_amdgcn_mfma_f64_16x16x4f64(Ac[o], bc, ac, 0, 0, 0);
         as = __builtin_amdgcn_mfma_f64_16x16x4f64(As[o], bs, as, 0, 0, 0);
-      }
       }
     }
     uc[j] = ac; us[j] = as;
@@ -384,6 +415,66 @@ __device__ __forceinline__ void dft_stage2(const int w, const int lane, const Pr
   const int ST = g.ST, Kc = g.Kc, M1 = g.M1;
   const int n_mt2 = g.N1 >> 4, n_nt2 = M1 >> 4;
   const int n_t2 = n_mt2 * n_nt2;
+  if constexpr (TABMODE == 2) {
+    // two tiles at a time, as in dft_stage1
+    struct Tile { const double* a_p; uint32_t m8, d8; bool on; };
+    const uint32_t n8 = 8u * (uint32_t)g.bw;
+    auto setup = [&](const int j) {
+      Tile x{TT, 0u, 0u, false};
+      const int t = w + j * NW;
+      x.on = (j < MAXT) && (t < n_t2) && !(a.dbg & 4);
+      if (x.on) {
+        const int nt = tile_div(t, g.q_mt2), mt = t - nt * n_mt2;
+        x.a_p = TT + l4 * ST + 16 * mt + l15;
+        const uint32_t xx = mod_magic((uint32_t)(16 * nt + l15), (uint32_t)g.bw, sc.m_bw);
+        x.m8 = 8u * mod_magic((uint32_t)l4 * xx, (uint32_t)g.bw, sc.m_bw);
+        x.d8 = 8u * mod_magic(4u * xx, (uint32_t)g.bw, sc.m_bw);
+      }
+      return x;
+    };
+    auto fetch = [&](Tile& x, const int k0, double& a1, double& a2, double& b1, double& b2) {
+      const char* tb = (const char*)tabG + x.m8;
+      a1 = x.a_p[k0 * ST]; a2 = x.a_p[(Kc + k0) * ST]; b1 = *(const double*)tb; b2 = *(const double*)(tb + 8 * kT1S);
+      x.m8 += x.d8;
+      x.m8 = min(x.m8, x.m8 - n8);
+    };
+#pragma unroll
+    for (int j = 0; j < MAXT; j += 2) {
+      Tile A = setup(j), B = setup(j + 1);
+      v4f64 eA = {0.0, 0.0, 0.0, 0.0}, oA = eA, eB = eA, oB = eA;
+      if (A.on && B.on) {
+        for (int k0 = 0; k0 < Kc; k0 += 4) {
+          double a1, a2, b1, b2, a3, a4, b3, b4;
+          fetch(A, k0, a1, a2, b1, b2);
+          fetch(B, k0, a3, a4, b3, b4);
+          eA = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, eA, 0, 0, 0);
+          oA = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, oA, 0, 0, 0);
+          eB = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, eB, 0, 0, 0);
+          oB = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, b4, oB, 0, 0, 0);
+        }
+      } else if (A.on) {
+        int k0 = 0;
+        for (; k0 + 8 <= Kc; k0 += 8) {
+          double a1, a2, b1, b2, a3, a4, b3, b4;
+          fetch(A, k0, a1, a2, b1, b2);
+          fetch(A, k0 + 4, a3, a4, b3, b4);
+          eA = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, eA, 0, 0, 0);
+          oA = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, oA, 0, 0, 0);
+          eA = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, eA, 0, 0, 0);
+          oA = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, b4, oA, 0, 0, 0);
+        }
+        if (k0 < Kc) {
+          double a1, a2, b1, b2;
+          fetch(A, k0, a1, a2, b1, b2);
+          eA = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, eA, 0, 0, 0);
+          oA = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, oA, 0, 0, 0);
+        }
+      }
+      fe[j] = eA; fo[j] = oA;
+      if (j + 1 < MAXT) { fe[j + 1] = eB; fo[j + 1] = oB; }
+    }
+    return;
+  }
   const double* __restrict__ GC = a.tables + sc.g_off;       // [Kc][M1]
   const double* __restrict__ GS = GC + Kc * M1;
 #pragma unroll
@@ -395,34 +486,6 @@ __device__ __forceinline__ void dft_stage2(const int w, const int lane, const Pr
       const double* a_p = TT + l4 * ST + 16 * mt + l15;
       const double* gc_p = GC + l4 * M1 + 16 * nt + l15;
       const double* gs_p = GS + l4 * M1 + 16 * nt + l15;
-      const uint32_t n8 = 8u * (uint32_t)g.bw;
-      const uint32_t xx = mod_magic((uint32_t)(16 * nt + l15), (uint32_t)g.bw, sc.m_bw);
-      uint32_t m8 = 8u * mod_magic((uint32_t)l4 * xx, (uint32_t)g.bw, sc.m_bw);
-      const uint32_t d8 = 8u * mod_magic(4u * xx, (uint32_t)g.bw, sc.m_bw);
-      if (TABMODE == 2) {
-        auto operands = [&](const int k0, double& a1, double& a2, double& b1, double& b2) {
-          const char* tb = (const char*)tabG + m8;
-          a1 = a_p[k0 * ST]; a2 = a_p[(Kc + k0) * ST]; b1 = *(const double*)tb; b2 = *(const double*)(tb + 8 * kT1S);
-          m8 += d8;
-          m8 = min(m8, m8 - n8);
-        };
-        int k0 = 0;
-        for (; k0 + 8 <= Kc; k0 += 8) {
-          double a1, a2, b1, b2, a3, a4, b3, b4;
-          operands(k0, a1, a2, b1, b2);
-          operands(k0 + 4, a3, a4, b3, b4);
-          ae = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, ae, 0, 0, 0);
-          ao = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, ao, 0, 0, 0);
-          ae = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, ae, 0, 0, 0);
-          ao = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, b4, ao, 0, 0, 0);
-        }
-        if (k0 < Kc) {
-          double a1, a2, b1, b2;
-          operands(k0, a1, a2, b1, b2);
-          ae = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, ae, 0, 0, 0);
-          ao = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, ao, 0, 0, 0);
-        }
-      } else {
 #pragma unroll 2
       for (int k0 = 0; k0 < Kc; k0 += 4) {
         double gc, gs;
@@ -434,7 +497,6 @@ __device__ __forceinline__ void dft_stage2(const int w, const int lane, const Pr
         }
         ae = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p[k0 * ST], gc, ae, 0, 0, 0);
         ao = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p[(Kc + k0) * ST], gs, ao, 0, 0, 0);
-      }
       }
     }
     fe[j] = ae; fo[j] = ao;
