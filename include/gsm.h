@@ -221,8 +221,9 @@ int gsm_last_run_fused(gsm_handle h);
 /* Which step kernels this handle's static fields and block table select (decided once per table, for gsm_run_replay and
  * gsm_run_philox alike, so that fused == propose + replay holds bit for bit): 1 = the strip kernels (chain_strip_kernel.hip:
  * 512-thread workgroups, two chains per CU, candidate bed in a (bh + 2) x (bw + 2) LDS tile), 0 = the flux-tile kernels
- * (1024-thread workgroups, one chain per CU; block tables whose strips would exceed 16 rows or whose proposal work area
- * exceeds 80 KiB; GSM_STRIP=0).  Needs gsm_set_static and gsm_set_blocks.  Same arithmetic per cell (MCMC.py:1279-1360,
+ * (1024-thread workgroups, one chain per CU: grids whose packed static operands, 48 bytes per cell, exceed an XCD's 4 MiB L2
+ * -- more than 87 381 cells --, block tables whose strips would exceed 16 rows or whose proposal work area exceeds 80 KiB,
+ * GSM_STRIP=0).  Needs gsm_set_static and gsm_set_blocks.  Same arithmetic per cell (MCMC.py:1279-1360,
  * Topography.py:592-600); the window sums of a step are taken in another order (loss within 1e-15 relative). */
 int gsm_strip_active(gsm_handle h);
 

@@ -53,7 +53,11 @@ bool strip_table_ok(const StaticFields& S, const BlockTable& B, int lds_main, in
   static int on = -1;
   if (on < 0) { const char* v = getenv("GSM_STRIP"); on = v ? atoi(v) : 1; }
   const size_t lds = ((size_t)std::max(lds_main, strip_tile_len(B)) + kStripAux) * sizeof(double);
-  return on && S.sA != nullptr && (uint64_t)S.H * S.W * 48u < 0x80000000ull && B.n_sizes <= 64 && strip::table_ok(B.max_bh, B.max_bw) &&
+  // The strip pass streams the static operands row by row, one row ahead: that hides an L2 hit, not a trip to the Infinity Cache
+  // or HBM.  The three packed planes (48 bytes per cell) must fit an XCD's 4 MiB L2 (256 x 256: 3 MiB); on larger grids the
+  // flux-tile kernels, which request a whole tile's operands at once, are faster (1024 x 1024, fp32 state: 12.8 M against 10.4 M
+  // chain-steps/s; 512 x 512 behind the Cholesky generator: 2.77 M against 2.75 M).
+  return on && S.sA != nullptr && (uint64_t)S.H * S.W * 48u <= (4ull << 20) && B.n_sizes <= 64 && strip::table_ok(B.max_bh, B.max_bw) &&
          B.max_bh <= kT1S && B.max_bw <= kT1S && lds <= 80 * 1024 && 2 * tiles1_max <= kSW * kSUPW && tiles2_max <= kSW * kSMAXT;
 }
 
