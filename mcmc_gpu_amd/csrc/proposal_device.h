@@ -189,12 +189,18 @@ __device__ __forceinline__ void coef_items(const int t, const int i_lo, const in
   double* __restrict__ Mi = Mr + plane;
   const int SX = g.SX, bh = g.bh, bw = g.bw, hh = g.hh, hw = g.hw, ncol = g.ncol, nrow = g.nrow;
   if (pad) {
-    const int npad = g.KR * g.M1;
+    // zero padding of the [KR][M1] operand grid around the nrow x ncol coefficients: the (at most 3) rows below them, whole,
+    // and the (at most 15) columns to their right -- 16 columns x NTH / 16 rows per pass, no division
+    const int M1 = g.M1, KR = g.KR;
     const uint32_t m_m1 = sc.m_m1;
-    for (int i = t; i < npad; i += NTH) {
-      const int ky = (int)__umulhi((uint32_t)i, m_m1);
-      const int kx = i - ky * g.M1;
-      if (ky >= nrow || kx >= ncol) {
+    for (int i = t; i < (KR - nrow) * M1; i += NTH) {
+      const int dy = (int)__umulhi((uint32_t)i, m_m1);
+      const int o = (nrow + dy) * SX + (i - dy * M1);
+      Pr[o] = 0.0; Pi[o] = 0.0; Mr[o] = 0.0; Mi[o] = 0.0;
+    }
+    const int kx = ncol + (t & 15);
+    if (kx < M1) {
+      for (int ky = t >> 4; ky < nrow; ky += NTH / 16) {
         const int o = ky * SX + kx;
         Pr[o] = 0.0; Pi[o] = 0.0; Mr[o] = 0.0; Mi[o] = 0.0;
       }

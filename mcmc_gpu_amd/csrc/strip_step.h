@@ -221,32 +221,27 @@ __device__ __forceinline__ void load_state(const Lane& L_in, const int n, const 
   const int W = fresh_s(W_in);
   const WriteMasks wm = write_masks(L);
   const bool colown = has(L, kFColOwn);
+  // Row by row, in the order phase A consumes them (loads return in the order they were issued).  The out-of-range offset lives
+  // in a register (a literal is re-materialised before every select), the own-column offsets are selected once, and a row's
+  // three loads share its compares: 5 vector instructions per row for three loads.
+  uint32_t oob = kOOB;
+  asm volatile("" : "+v"(oob));
+  const uint32_t ownS = colown ? L.cell0 * (uint32_t)sizeof(TS) : oob, own16 = colown ? L.cell0 * 16u : oob;
 #pragma unroll
   for (int jj = 0; jj < kNR + 2; ++jj) {
     vb[jj] = 0.0;
+    if (jj >= 1 && jj <= kNR) ve[jj - 1] = 0.0;
+    if (jj >= 1 && jj <= kNA) a2[jj - 1] = make_double2(0.0, 0.0);
     if (jj <= n + 1) {
-      uint32_t off, soff;
+      uint32_t off, soff, off16, soff16;
       row_offsets<INTERIOR>(L, jj, W, (uint32_t)sizeof(TS), off, soff);
-      vb[jj] = RowIO<TS>::load(r_bed, cell_written<INTERIOR>(L, wm, jj) ? off : kOOB, soff);
-    }
-  }
-#pragma unroll
-  for (int R = 1; R <= kNA; ++R) {
-    a2[R - 1] = make_double2(0.0, 0.0);
-    if (R <= n) {
-      uint32_t off, soff;
-      row_offsets<INTERIOR>(L, R, W, 16u, off, soff);
-      a2[R - 1] = ld_f64x2(r_st, (row_own(L, R) && colown) ? off : kOOB, soff);
-    }
-  }
-  // the carried energies last: they are only summed, at the end of phase A (loads return in the order they were issued)
-#pragma unroll
-  for (int R = 1; R <= kNR; ++R) {
-    ve[R - 1] = 0.0;
-    if (R <= n) {
-      uint32_t off, soff;
-      row_offsets<INTERIOR>(L, R, W, (uint32_t)sizeof(TS), off, soff);
-      ve[R - 1] = RowIO<TS>::load(r_en, (row_own(L, R) && colown) ? off : kOOB, soff);
+      row_offsets<INTERIOR>(L, jj, W, 16u, off16, soff16);
+      vb[jj] = RowIO<TS>::load(r_bed, cell_written<INTERIOR>(L, wm, jj) ? off : oob, soff);
+      if (jj >= 1 && jj <= kNR) {
+        const bool ro = row_own(L, jj);
+        if (jj <= kNA) a2[jj - 1] = ld_f64x2(r_st, ro ? (INTERIOR ? own16 : (colown ? off16 : oob)) : oob, soff16);
+        ve[jj - 1] = RowIO<TS>::load(r_en, ro ? (INTERIOR ? ownS : (colown ? off : oob)) : oob, soff);
+      }
     }
   }
 }
@@ -263,6 +258,9 @@ __device__ __forceinline__ void phase_a(const Lane& L_in, const int n, const int
   const int W = fresh_s(W_in);
   const WriteMasks wm = write_masks(L);
   const bool colown = has(L, kFColOwn);
+  uint32_t oob = kOOB;
+  asm volatile("" : "+v"(oob));
+  const uint32_t own16 = colown ? L.cell0 * 16u : oob;
   guard = false;
   upd_bits = 0u;
   const int ts = bw + 2;
@@ -276,7 +274,7 @@ __device__ __forceinline__ void phase_a(const Lane& L_in, const int n, const int
         if (jj + kNA <= kNR && jj + kNA <= n) {             // (wupd, surf) of row jj + kNA into the slot just read
           uint32_t off, soff;
           row_offsets<INTERIOR>(L, jj + kNA, W, 16u, off, soff);
-          a2[(jj - 1) % kNA] = ld_f64x2(r_st, (row_own(L, jj + kNA) && colown) ? off : kOOB, soff);
+          a2[(jj - 1) % kNA] = ld_f64x2(r_st, row_own(L, jj + kNA) ? (INTERIOR ? own16 : (colown ? off : oob)) : oob, soff);
         }
         const double f = field(jj, own);
         const bool upd = own && (__builtin_bit_cast(uint64_t, A2.x) != kNoUpdBits);
@@ -425,14 +423,17 @@ __device__ __forceinline__ void commit(const Lane& L_in, const int n, const int 
   const Lane L = fresh(L_in);
   const int W = fresh_s(W_in);
   const bool colown = has(L, kFColOwn);
+  uint32_t oob = kOOB;
+  asm volatile("" : "+v"(oob));
+  const uint32_t ownS = colown ? L.cell0 * (uint32_t)sizeof(TS) : oob;
 #pragma unroll
   for (int R = 1; R <= kNR; ++R) {
     if (R > n) continue;
     uint32_t off, soff;
     row_offsets<INTERIOR>(L, R, W, (uint32_t)sizeof(TS), off, soff);
     const bool upd = (upd_bits >> R) & 1u;
-    RowIO<TS>::store(r_en, (row_own(L, R) && colown) ? off : kOOB, soff, en[R - 1]);
-    RowIO<TS>::store(r_bed, upd ? off : kOOB, soff, vn[R - 1]);
+    RowIO<TS>::store(r_en, row_own(L, R) ? (INTERIOR ? ownS : (colown ? off : oob)) : oob, soff, en[R - 1]);
+    RowIO<TS>::store(r_bed, upd ? off : oob, soff, vn[R - 1]);
     if (RS) {
       uint32_t off4, soff4;
       row_offsets<INTERIOR>(L, R, W, 4u, off4, soff4);
