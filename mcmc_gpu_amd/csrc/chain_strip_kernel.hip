@@ -44,7 +44,7 @@ constexpr int kSMAXT = 16 / kSW;  // stage-2 tiles per wave
 
 static int strip_tile_len(const BlockTable& B) { return (B.max_bh + 2) * (B.max_bw + 2); }   // candidate-bed tile: block + halo ring
 static int strip_main_len(const FusedArgs& a) { return std::max(a.P.lds_main, strip_tile_len(a.T.B)); }
-constexpr int kStripAux = 16 + 32 + 16 + kMathTabDoubles + 4 * kT1S;     // wave partials (+ the carried sums), proposal reductions, math table, 1-D twiddle tables
+constexpr int kStripAux = 16 + 32 + 16 + kMathTabDoubles + 4 * kT1S + kMask1D;     // wave partials (+ the carried sums), proposal reductions, math table, 1-D twiddle tables, 1-D edge mask
 size_t fused_strip_lds_doubles(const FusedArgs& a) { return (size_t)strip_main_len(a) + kStripAux; }
 
 // One decision per (static fields, block table): both strip kernels or neither (the sums of a step are taken in another
@@ -58,7 +58,7 @@ bool strip_table_ok(const StaticFields& S, const BlockTable& B, int lds_main, in
   // flux-tile kernels, which request a whole tile's operands at once, are faster (1024 x 1024, fp32 state: 12.8 M against 10.4 M
   // chain-steps/s; 512 x 512 behind the Cholesky generator: 2.77 M against 2.75 M).
   return on && S.sA != nullptr && (uint64_t)S.H * S.W * 48u <= (4ull << 20) && B.n_sizes <= 64 && strip::table_ok(B.max_bh, B.max_bw) &&
-         B.max_bh <= kT1S && B.max_bw <= kT1S && lds <= 80 * 1024 && 2 * tiles1_max <= kSW * kSUPW && tiles2_max <= kSW * kSMAXT;
+         B.max_bh <= kT1S && B.max_bw <= kT1S && (B.masks == nullptr || B.mask1d != nullptr) && lds <= 80 * 1024 && 2 * tiles1_max <= kSW * kSUPW && tiles2_max <= kSW * kSMAXT;
 }
 
 typedef const __attribute__((address_space(4))) PropScalars* srec_t;
@@ -99,6 +99,7 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
   double* __restrict__ carry = red2 + 32;
   double* __restrict__ mtab = red2 + 32 + 16;                      // [kMathTabDoubles] log / sincos table (math_tables.h)
   double* __restrict__ t1 = mtab + kMathTabDoubles;                // [4][kT1S] 1-D twiddle tables of the step's block: cos, sin (height), cos, -sin (width)
+  double* __restrict__ m1 = t1 + 4 * kT1S;                         // [kMask1D] edge mask of the step's block size by distance to the block border
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
     {
       const cargs_t K = kargs();
       const double* __restrict__ g1 = K->P.tab1d;
+      if (tid >= kST - kMask1D) m1[tid - (kST - kMask1D)] = K->P.B.mask1d[rec->si * kMask1D + tid - (kST - kMask1D)];
       if (tid < 2 * s_bh) t1[(tid < s_bh) ? tid : kT1S + tid - s_bh] = g1[rec->t1h_off + tid];
       else if (tid >= 256 && tid < 256 + 2 * s_bw) {
         const int i = tid - 256;
@@ -202,11 +204,10 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
       const PropGeom pg = prop_geom(pa, q.bh, q.bw);
       const int bw = q.bw;
       v4f64 fe[kSMAXT], fo[kSMAXT];
-      double mreg[kSMAXT][8];
+      const double mreg[kSMAXT][8] = {};        // not used: the edge mask comes from the 1-D table in LDS (m1)
       relaunder();
       const int ln = ptid & 63;
       dft_stage2<kSW, kSMAXT, 2>(wave, ln, pa, q, pg, lds, t1 + 2 * kT1S, fe, fo);
-      mask_prefetch<kSW, kSMAXT>(wave, ln, pa, q, pg, mreg);
       double mean;
       const double gain = standardise<kSW, kSMAXT>(wave, ln, q, pg, dc0, red2, fe, fo, mean);     // contains a barrier
       NoiseIn nz{nullptr, nullptr, nullptr};
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
         if (nb) nz.nug = nb + noise0 + (int64_t)s * F->noise_stride;
       }
       const bool with_nugget = NOISE ? (nz.nug != nullptr) : (pa.rf.nugget_max > 0.0);
-      emit_field<kSW, kSMAXT, true>(wave, ln, pa, q, pg, fe, fo, mreg, mean, gain, with_nugget, lds, [bw](int y, int x) { return (y + 1) * (bw + 2) + x + 1; });
+      emit_field<kSW, kSMAXT, 2>(wave, ln, pa, q, pg, fe, fo, mreg, mean, gain, with_nugget, lds, [bw](int y, int x) { return (y + 1) * (bw + 2) + x + 1; }, m1);
       if (with_nugget) {
         __syncthreads();
         relaunder();

@@ -24,6 +24,7 @@ struct gsm_context {
   int32_t *d_bh = nullptr, *d_bw = nullptr;
   int64_t* d_mask_off = nullptr;
   double* d_masks = nullptr;
+  double* d_mask1d = nullptr;    // [n_sizes][kMask1D]: the masks as a function of the distance to the block border, if they are one
   double* d_tables = nullptr;
   int32_t *d_fy_off = nullptr, *d_g_off = nullptr;
   double* d_tab1d = nullptr; int32_t* d_t1_off = nullptr;   // 1-D twiddle tables of the strip kernel's DFT stages
@@ -135,6 +136,7 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_bw) hipFree(h->d_bw);
   if (h->d_mask_off) hipFree(h->d_mask_off);
   if (h->d_masks) hipFree(h->d_masks);
+  if (h->d_mask1d) hipFree(h->d_mask1d);
   if (h->d_tables) hipFree(h->d_tables);
   if (h->d_fy_off) hipFree(h->d_fy_off);
   if (h->d_g_off) hipFree(h->d_g_off);
@@ -252,9 +254,37 @@ extern "C" int gsm_set_blocks(gsm_handle h, int32_t n_sizes, const int32_t* bh, 
   if (edge_masks_packed && mask_offsets) {
     HIPCHK(h, dup_device(&h->d_mask_off, mask_offsets, (size_t)n_sizes, st));
     HIPCHK(h, dup_device(&h->d_masks, edge_masks_packed, (size_t)mask_total, st));
+    // The reference's edge masks are a function of the distance to the nearest border cell of the block (get_edge_masks,
+    // MCMC.py:583-621): mask[y][x] = T[min(y, bh - 1 - y, x, bw - 1 - x)].  Checked value for value here; if every mask of the
+    // table has that form, the strip kernel reads the 64-entry T from LDS instead of 8 bytes per cell from a 51 KB table.
+    if (h->d_mask1d) { hipFree(h->d_mask1d); h->d_mask1d = nullptr; }
+    {
+      std::vector<double> hm((size_t)mask_total);
+      HIPCHK(h, hipMemcpyAsync(hm.data(), edge_masks_packed, sizeof(double) * (size_t)mask_total, hipMemcpyDefault, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      std::vector<double> t1((size_t)n_sizes * kMask1D, 0.0);
+      bool one_d = true;
+      for (int i = 0; i < n_sizes && one_d; ++i) {
+        const double* m = hm.data() + mask_offsets[i];
+        const int H = bh[i], W = bw[i];
+        if ((std::min(H, W) - 1) / 2 >= kMask1D) { one_d = false; break; }
+        std::vector<char> have(kMask1D, 0);
+        for (int y = 0; y < H && one_d; ++y)
+          for (int x = 0; x < W; ++x) {
+            const int d = std::min(std::min(y, H - 1 - y), std::min(x, W - 1 - x));
+            const double v = m[(size_t)y * W + x];
+            double& t = t1[(size_t)i * kMask1D + d];
+            if (!have[d]) { have[d] = 1; t = v; }
+            else if (memcmp(&t, &v, sizeof(double)) != 0) { one_d = false; break; }
+          }
+      }
+      if (one_d) HIPCHK(h, dup_device(&h->d_mask1d, t1.data(), t1.size(), st));
+      HIPCHK(h, hipStreamSynchronize(st));
+    }
   } else {
     if (h->d_masks) { hipFree(h->d_masks); h->d_masks = nullptr; }
     if (h->d_mask_off) { hipFree(h->d_mask_off); h->d_mask_off = nullptr; }
+    if (h->d_mask1d) { hipFree(h->d_mask1d); h->d_mask1d = nullptr; }
   }
   // DFT operand tables of the proposal kernel, one set per distinct block height / width, folded to indices <= n/2
   // and zero padded to the MFMA tile grid (dimension formulas mirror propose_kernel):
@@ -347,7 +377,7 @@ extern "C" int gsm_set_blocks(gsm_handle h, int32_t n_sizes, const int32_t* bh, 
     HIPCHK(h, hipStreamSynchronize(st));       // the host vectors end with this block
   }
   HIPCHK(h, hipStreamSynchronize(st));
-  h->B.bh = h->d_bh; h->B.bw = h->d_bw; h->B.masks = h->d_masks; h->B.mask_off = h->d_mask_off;
+  h->B.bh = h->d_bh; h->B.bw = h->d_bw; h->B.masks = h->d_masks; h->B.mask_off = h->d_mask_off; h->B.mask1d = h->d_mask1d;
   h->B.n_sizes = n_sizes; h->B.max_bh = max_bh; h->B.max_bw = max_bw;
   h->tile_cap = cap;
   h->field_stride = (int64_t)max_bh * max_bw;

@@ -49,6 +49,9 @@ struct BlockTable {
   const int32_t* bw;      // device, n_sizes
   const double* masks;    // device, packed edge masks
   const int64_t* mask_off;  // device, n_sizes
+  const double* mask1d;   // device [n_sizes][64] or nullptr: the edge masks as a function of the distance to the block's border,
+                          // mask[y][x] = mask1d[size][min(y, bh - 1 - y, x, bw - 1 - x)] -- set when every mask has that form
+                          // (get_edge_masks, MCMC.py:583-621: a logistic function of the distance to the nearest border cell)
   int n_sizes;
   int max_bh, max_bw;
 };
@@ -271,6 +274,7 @@ hipError_t launch_noise_chain_scalars(const ProposeArgs& a, const int32_t* size_
 hipError_t launch_step_strip(const StepArgs& a, hipStream_t st);
 hipError_t launch_resampled_from_records(const FusedArgs& a, hipStream_t st);
 bool strip_table_ok(const StaticFields& S, const BlockTable& B, int lds_main, int tiles1_max, int tiles2_max);
+constexpr int kMask1D = 64;    // entries per block size of BlockTable::mask1d
 bool fused_supported(const FusedArgs& a);
 int propose_max_tiles_per_wave();
 int propose_max_tiles1_per_wave();

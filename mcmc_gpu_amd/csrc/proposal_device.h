@@ -603,11 +603,13 @@ __device__ __forceinline__ double standardise(const int w, const int lane, const
 // out = (t + n * sqrt(nug)) * mask with t = (field - mean) * gain.  Without a nugget the finished value is stored
 // directly; with one, t is stored first and nugget_pass adds the nugget normals and applies the mask -- the same
 // operations in the same order.  Cell (y, x) goes to out[omap(y, x)], or nowhere if omap returns a negative index.
-template <int NW, int MAXT, bool TABLDS, class OMap>
+// MASKMODE: where the edge mask of a cell comes from -- 0 the packed table in global memory, 1 `mreg` (mask_prefetch), 2 a table
+// in LDS indexed by the cell's distance to the block border, m1d[min(y, bh - 1 - y, x, bw - 1 - x)] (BlockTable::mask1d).
+template <int NW, int MAXT, int MASKMODE, class OMap>
 __device__ __forceinline__ void emit_field(const int w, const int lane, const ProposeArgs& a, const PropScalars& sc, const PropGeom& g,
                                            const v4f64 (&fe)[MAXT], const v4f64 (&fo)[MAXT], const double (&mreg)[MAXT][8],
                                            const double mean, const double gain, const bool with_nugget,
-                                           double* __restrict__ out, OMap omap) {
+                                           double* __restrict__ out, OMap omap, const double* m1d = nullptr) {
   if (w < 0) return;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int bh = g.bh, bw = g.bw, hw = g.hw;
@@ -629,7 +631,10 @@ __device__ __forceinline__ void emit_field(const int w, const int lane, const Pr
           const int o = y * bw + xx;
           const int oi = omap(y, xx);
           const double v = ((half ? fo[j][q] : fe[j][q]) - mean) * gain;
-          if (oi >= 0) out[oi] = with_nugget ? v : v * (TABLDS ? mreg[j][2 * q + half] : mask[o]);
+          double mk;
+          if (MASKMODE == 2) mk = m1d[min(min(y, bh - 1 - y), min(xx, bw - 1 - xx))];
+          else mk = (MASKMODE == 1) ? mreg[j][2 * q + half] : mask[o];
+          if (oi >= 0) out[oi] = with_nugget ? v : v * mk;
         }
       }
     }
