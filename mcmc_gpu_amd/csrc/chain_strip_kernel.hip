@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
         const int64_t o = noise0 + (int64_t)s * F->noise_stride;
         nz.re = F->noise_re + o; nz.im = F->noise_im + o;
       }
-      coef_items<kST, NOISE>(ptid, 0, pg.nrow * pg.ncol, true, pa, q, pg, seed, pa.step0 + s, lds, pa.lds_x_half, nz, mtab);
+      coef_items<kST, NOISE, true>(ptid, 0, pg.nrow * pg.ncol, true, pa, q, pg, seed, pa.step0 + s, lds, pa.lds_x_half, nz, mtab);
     }
     // Stores of an accepted step must have landed before a later step reads an overlapping window.  They were issued a
     // whole coefficient phase ago; the wait is free, and the barriers that follow order it across the waves.
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
         const cargs_t K = kargs();
         const ProposeArgs pa = load_cs(&K->P);
         relaunder();
-        dft_tt_write<kSW, kSUPW, true>(wave, ptid & 63, prop_geom(pa, s_bh, s_bw), lds, uc, us);
+        dft_tt_write<kSW, kSUPW>(wave, ptid & 63, prop_geom(pa, s_bh, s_bw), lds, uc, us);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
       else strip::load_state<TS, false>(L, cfg.n, gW, r_bed, r_en, r_st, vb, ve, a2);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // field tile complete; the state loads stay in flight
       const int ts = s_bw + 2;
-      auto field = [&](int jj, bool in) { return in ? lds[L.tidx + jj * ts] : 0.0; };
+      auto field = [&](int jj, bool) { return lds[L.tidx + jj * ts]; };      // unconditional: a lane without the cell discards the value
       if (dbg & 256) { upd_bits = 0u; acc_old = 0.0; guard = false; }
       else if (G.interior) strip::phase_a<TS, true>(L, cfg.n, gW, s_bw, r_st, field, lds, vb, ve, a2, upd_bits, acc_old, guard);
       else strip::phase_a<TS, false>(L, cfg.n, gW, s_bw, r_st, field, lds, vb, ve, a2, upd_bits, acc_old, guard);

@@ -179,7 +179,10 @@ __device__ __forceinline__ PropGeom prop_geom(const ProposeArgs& a, int bh, int 
 // columns they are a conjugate pair built from the same two draws.  Thread t of NTH handles items i_lo + t, + NTH, ... below
 // i_hi, and -- if `pad` -- the zero padding of the [KR][M1] operand grid.  The four planes may live in LDS or in global
 // memory (plane stride `plane`, row stride SX).
-template <int NTH, bool NOISE_IN>
+// FOLD_CK: the Hermitian-half factor c_kx (1 for kx in {0, bw / 2}, else 2) of the stage-2 operand table is applied here, to the
+// spectral amplitude -- one multiply per work item; stage 1 is linear, so T^T comes out scaled exactly as if its rows had been
+// doubled (powers of two commute with every rounding) and TABMODE 2 of dft_stage2 reads plain cos / sin.
+template <int NTH, bool NOISE_IN, bool FOLD_CK = false>
 __device__ __forceinline__ void coef_items(const int t, const int i_lo, const int i_hi, const bool pad, const ProposeArgs& a,
                                            const PropScalars& sc, const PropGeom& g, const uint64_t seed, const int64_t step,
                                            double* __restrict__ Pr, const int plane, const NoiseIn noise, const double* mt) {
@@ -218,6 +221,7 @@ __device__ __forceinline__ void coef_items(const int t, const int i_lo, const in
     double ar, ai, br = 0.0, bi = 0.0;   // X[ky], X[bh - ky]
     if (NOISE_IN) {
       amp = spectral_amp(P, sc, k2, mt);
+      if (FOLD_CK && kx != 0 && kx != hw) amp = 2.0 * amp;
       const int nky = (ky == 0) ? 0 : kyc, nkx = (kx == 0) ? 0 : bw - kx;      // -k modulo the block shape
       ar = amp * (0.5 * (noise.re[ky * bw + kx] + noise.re[nky * bw + nkx]));
       ai = amp * (0.5 * (noise.im[ky * bw + kx] - noise.im[nky * bw + nkx]));
@@ -235,6 +239,7 @@ __device__ __forceinline__ void coef_items(const int t, const int i_lo, const in
         if (!paired) { h1 = 0.0; h2 = 0.0; }
         amp = spectral_amp(P, sc, k2, mt);
       }
+      if (FOLD_CK && kx != 0 && kx != hw) amp = 2.0 * amp;
       if (kx > 0 && kx < hw) {
         ar = amp * (g1 * M_SQRT1_2); ai = amp * (g2 * M_SQRT1_2);
         if (paired) { br = amp * (h1 * M_SQRT1_2); bi = amp * (h2 * M_SQRT1_2); }

@@ -214,7 +214,8 @@ __device__ __forceinline__ bool cell_written(const Lane& L, const WriteMasks& m,
 // cell of row R, a2[R - 1] = (wupd, surf) of the own cells of rows 1 .. kNA (a ring: part 2 requests row R + kNA when it is
 // done with row R).  0 where the lane has no such cell.
 constexpr int kNA = 4;
-template <typename TS, bool INTERIOR>
+// PARTS: 1 = the bed, 2 = carried energy and (wupd, surf), 3 = both, row by row
+template <typename TS, bool INTERIOR, int PARTS = 3>
 __device__ __forceinline__ void load_state(const Lane& L_in, const int n, const int W_in, const rsrc_t r_bed, const rsrc_t r_en, const rsrc_t r_st,
                                            double (&vb)[kNR + 2], double (&ve)[kNR], double2 (&a2)[kNA]) {
   const Lane L = fresh(L_in);
@@ -229,15 +230,15 @@ __device__ __forceinline__ void load_state(const Lane& L_in, const int n, const 
   const uint32_t ownS = colown ? L.cell0 * (uint32_t)sizeof(TS) : oob, own16 = colown ? L.cell0 * 16u : oob;
 #pragma unroll
   for (int jj = 0; jj < kNR + 2; ++jj) {
-    vb[jj] = 0.0;
-    if (jj >= 1 && jj <= kNR) ve[jj - 1] = 0.0;
-    if (jj >= 1 && jj <= kNA) a2[jj - 1] = make_double2(0.0, 0.0);
+    if (PARTS & 1) vb[jj] = 0.0;
+    if ((PARTS & 2) && jj >= 1 && jj <= kNR) ve[jj - 1] = 0.0;
+    if ((PARTS & 2) && jj >= 1 && jj <= kNA) a2[jj - 1] = make_double2(0.0, 0.0);
     if (jj <= n + 1) {
       uint32_t off, soff, off16, soff16;
       row_offsets<INTERIOR>(L, jj, W, (uint32_t)sizeof(TS), off, soff);
       row_offsets<INTERIOR>(L, jj, W, 16u, off16, soff16);
-      vb[jj] = RowIO<TS>::load(r_bed, cell_written<INTERIOR>(L, wm, jj) ? off : oob, soff);
-      if (jj >= 1 && jj <= kNR) {
+      if (PARTS & 1) vb[jj] = RowIO<TS>::load(r_bed, cell_written<INTERIOR>(L, wm, jj) ? off : oob, soff);
+      if ((PARTS & 2) && jj >= 1 && jj <= kNR) {
         const bool ro = row_own(L, jj);
         if (jj <= kNA) a2[jj - 1] = ld_f64x2(r_st, ro ? (INTERIOR ? own16 : (colown ? off16 : oob)) : oob, soff16);
         ve[jj - 1] = RowIO<TS>::load(r_en, ro ? (INTERIOR ? ownS : (colown ? off : oob)) : oob, soff);
