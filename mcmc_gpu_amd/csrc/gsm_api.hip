@@ -38,7 +38,7 @@ struct gsm_context {
   // gsm_sgs_iterate: the captured launch sequence of one batch (hipGraph), keyed by the bytes of its gsm_sgs_batch + n_iters
   int sgs_ktype = 0; const double* sgs_gmean = nullptr;        // gsm_sgs_set_kriging
   std::vector<char> sgs_graph_key; hipGraphExec_t sgs_graph_exec = nullptr; int sgs_graph_replays = 0;
-  uint64_t* d_pcg_tab = nullptr;   // gsm_draw_pcg64: LCG jump table (512 words) + ziggurat tables (768 words)
+  uint64_t* d_pcg_tab = nullptr;   // gsm_draw_pcg64: LCG jump table (kPcgJumpWords) + ziggurat tables (768 words)
   int32_t* d_k2_off = nullptr;
   double k2_resolution = 0.0;
   PropScalars* d_scalars[2] = {nullptr, nullptr};
@@ -888,10 +888,10 @@ extern "C" int gsm_set_factors(gsm_handle h, int32_t n_classes, const double* co
 
 static int ensure_pcg_tables(gsm_handle h) {
   if (h->d_pcg_tab) return GSM_OK;
-  std::vector<uint64_t> tab(4 * 128 + 768);
+  std::vector<uint64_t> tab(kPcgJumpWords + 768);
   const uint64_t* zig = nullptr;
   pcg64_host_tables(tab.data(), &zig);
-  memcpy(tab.data() + 512, zig, 768 * sizeof(uint64_t));
+  memcpy(tab.data() + kPcgJumpWords, zig, 768 * sizeof(uint64_t));
   HIPCHK(h, hipMalloc(&h->d_pcg_tab, tab.size() * sizeof(uint64_t)));
   HIPCHK(h, hipMemcpy(h->d_pcg_tab, tab.data(), tab.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   return GSM_OK;
@@ -914,7 +914,7 @@ extern "C" int gsm_draw_pcg64(gsm_handle h, int32_t n_steps, const gsm_rf_params
   PcgDrawArgs a{};
   a.H = h->H; a.W = h->W; a.n_chains = h->n_chains; a.n_steps = n_steps; a.n_sizes = h->B.n_sizes; a.rf = *rf;
   a.bh = h->B.bh; a.bw = h->B.bw; a.rf_state = rf_state; a.ch_state = chain_state; a.region_mask = region_mask;
-  a.jump = h->d_pcg_tab; a.zig = h->d_pcg_tab + 512;
+  a.jump = h->d_pcg_tab; a.zig = h->d_pcg_tab + kPcgJumpWords;
   a.size_idx = size_idx; a.centre = centre; a.u = u; a.rf_scalars = rf_scalars;
   a.noise_re = noise_re; a.noise_im = noise_im; a.nugget = (rf->nugget_max > 0.0) ? nugget_field : nullptr; a.field_stride = field_stride;
   a.err = h->d_err;
@@ -1073,7 +1073,7 @@ extern "C" int gsm_sgs_draw_pcg64(gsm_handle h, uint64_t* chain_state, int32_t n
   a.region_mask = region_mask; a.is_data = is_data; a.min_x = min_x; a.max_x = max_x; a.min_y = min_y; a.max_y = max_y;
   a.max_cells = max_cells; a.mathtab = nullptr;
   a.win = windows; a.blk = blocks; a.cell_off = cell_off; a.cell_cnt = cell_cnt; a.cells = cells; a.z = z; a.u = u; a.err = h->d_err;
-  HIPCHK(h, launch_sgs_draw_pcg64(a, chain_state, h->d_pcg_tab, h->d_pcg_tab + 512, (hipStream_t)stream));
+  HIPCHK(h, launch_sgs_draw_pcg64(a, chain_state, h->d_pcg_tab, h->d_pcg_tab + kPcgJumpWords, (hipStream_t)stream));
   return GSM_OK;
 }
 

@@ -175,6 +175,7 @@ struct PcgDrawArgs {
   int32_t* err;
 };
 hipError_t launch_pcg64_draw(const PcgDrawArgs& a, hipStream_t st);
+constexpr int kPcgJumpWords = 4 * 512;          // = 4 * pcg::kJump (pcg64_device.h; checked there where both are visible)
 void pcg64_host_tables(uint64_t* jump_out, const uint64_t** zig_out);
 struct SgsDrawArgs;
 hipError_t launch_sgs_draw_pcg64(const SgsDrawArgs& a, uint64_t* states, const uint64_t* jump, const uint64_t* zig, hipStream_t st);

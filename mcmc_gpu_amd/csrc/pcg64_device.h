@@ -49,7 +49,8 @@ GSM_PCG_HD uint64_t output_xsl_rr(u128 s) {
 }
 GSM_PCG_HD double to_double(uint64_t r) { return (double)(r >> 11) * (1.0 / 9007199254740992.0); }
 
-constexpr int kJump = 128;                  // jump table entries: (A_n, G_n) for n = 1 .. 128 at index n - 1
+constexpr int kJump = 512;                  // jump table entries: (A_n, G_n) for n = 1 .. 512 at index n - 1 (8 windows of 64 draws)
+constexpr int kJumpWave = 64;               // what a kernel with one wavefront per stream stages in LDS
 // host: fills tab[4 * (n - 1) ..] = A_n.lo, A_n.hi, G_n.lo, G_n.hi
 inline void build_jump_table(uint64_t* tab) {
   u128 A{1, 0}, G{0, 0};
@@ -294,6 +295,113 @@ struct Stream {
       }
       rank += min(got, need);
       s = lane_state(st, consumed);
+    }
+  }
+
+  // normals() with NW wavefronts per stream (a workgroup of NW x 64 threads; every wavefront holds the same Stream and calls this
+  // together): wavefront w decodes the window of draws 64 w + 1 .. 64 w + 64 ahead of `s` ON THE ASSUMPTION that every window
+  // before it is consumed whole -- true unless one of them is cut (before a tail start, before a wedge start in its last lane, at
+  // the end of the plane: 2-3 % of the windows).  Each wavefront analyses its window as normals() does and publishes (draws it
+  // would consume, normals it would produce); after a barrier every wavefront walks the NW entries in order -- the same uniform
+  // code everywhere -- and knows the rank its normals start at, whether its window counts at all (no cut before it), and the new
+  // rank; the last window that counts hands the state behind its consumed draws to the others through LDS.  A tail start at the
+  // head of window 0 is resolved by all wavefronts redundantly with sequential draws (1 normal in 3 700).
+  // A_wl / C_wl: jump constants of THIS lane of THIS wavefront (mult^(64 w + l + 1), inc * G_(64 w + l + 1)); xch: LDS, 2 NW + 4 words.
+  template <int NW>
+  __device__ __forceinline__ void normals_mw(int count, double loc, double scale, double* dst, int lane, int wave, u128 A_wl, u128 C_wl,
+                                             uint64_t* xch) {
+    const double zr = 3.6541528853610087963519472518, zinv = 0.27366123732975827203338247596;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int* info = (int*)xch;                      // info[2 w] = draws window w consumes if it counts whole, info[2 w + 1] = normals produced
+    uint64_t* st_x = xch + NW;                  // the state behind the last counted window
+    int rank = 0;
+    while (rank < count) {
+      const u128 st = add128(mul128(A_wl, s), C_wl);                        // the state 64 wave + lane + 1 draws ahead
+      const uint64_t raw = output_xsl_rr(st);
+      const int idx = (int)(raw & 0xff);
+      const uint64_t r8 = raw >> 8;
+      const uint64_t rabs = (r8 >> 1) & 0x000fffffffffffffull;
+      double x = (double)rabs * __builtin_bit_cast(double, zig[256 + idx]);
+      if (r8 & 1) x = -x;
+      const bool slow = !(rabs < zig[idx]);
+      const unsigned long long slow_mask = __ballot(slow), tail_mask = __ballot(slow && idx == 0);
+      int limit = 0;
+      unsigned long long pmask = 0ull;
+      bool produced = false;
+      if (!(tail_mask & 1ull)) {
+        unsigned long long start_mask = ~0ull;
+        for (unsigned long long t = slow_mask & ~tail_mask; t; t &= t - 1) {
+          const int bpos = __ffsll((long long)t) - 1;
+          if (((start_mask >> bpos) & 1ull) && bpos < 63) start_mask &= ~(1ull << (bpos + 1));
+        }
+        const unsigned long long wedge63 = (slow_mask & ~tail_mask) & start_mask & (1ull << 63);
+        const unsigned long long cut = (tail_mask & start_mask) | wedge63;
+        limit = cut ? (__ffsll((long long)cut) - 1) : 64;
+        const bool is_start = ((start_mask >> lane) & 1ull) && lane < limit;
+        const uint64_t raw_next = (uint64_t)(uint32_t)__shfl_down((int)(uint32_t)raw, 1, 64) |
+                                  ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(raw >> 32), 1, 64) << 32);
+        produced = is_start && !slow;
+        if (is_start && slow) {
+          const double f0 = __builtin_bit_cast(double, zig[512 + idx - 1]), f1 = __builtin_bit_cast(double, zig[512 + idx]);
+          produced = (f0 - f1) * to_double(raw_next) + f1 < exp(-0.5 * x * x);
+        }
+        pmask = __ballot(produced);
+      }
+      const int got = __popcll(pmask);
+      if (lane == 0) { info[2 * wave] = limit; info[2 * wave + 1] = got; }
+      __syncthreads();
+      if (info[0] == 0) {
+        // ---- the stream continues with a tail start: every wavefront resolves it with sequential draws -------------------
+        const uint64_t raw0 = next64();
+        const uint64_t rabs0 = ((raw0 >> 8) >> 1) & 0x000fffffffffffffull;
+        double val;
+        for (;;) {
+          const double u1 = next_double(), u2 = next_double();
+          const double xx = -zinv * log1p_fdlibm(-u1);
+          const double yy = -log1p_fdlibm(-u2);
+          if (yy + yy > xx * xx) { val = ((rabs0 >> 8) & 1) ? -(zr + xx) : zr + xx; break; }
+        }
+        if (wave == 0 && lane == 0 && dst) dst[rank] = loc + scale * val;
+        rank += 1;
+        __syncthreads();                                                    // info[] is rewritten by the next pass
+        continue;
+      }
+      // ---- which windows count, and where their normals go (uniform code, the same in every wavefront) -------------------
+      int base = rank, my_base = 0, last = 0, new_rank = rank;
+      bool open = true, mine = false, ends_here = false;
+#pragma unroll
+      for (int u = 0; u < NW; ++u) {
+        const int lim_u = info[2 * u], got_u = info[2 * u + 1];
+        if (open && lim_u > 0) {
+          if (u == wave) { mine = true; my_base = base; }
+          last = u;
+          const int need_u = count - base;
+          if (got_u >= need_u) { open = false; base = count; if (u == wave) ends_here = true; }   // the plane ends inside window u
+          else { base += got_u; if (lim_u < 64) open = false; }
+        } else {
+          open = false;
+        }
+      }
+      new_rank = base;
+      if (mine) {
+        const int need = count - my_base;
+        const int my = __popcll(pmask & below);
+        if (produced && my < need && dst) dst[my_base + my] = loc + scale * x;
+        if (wave == last) {
+          int consumed = limit;
+          if (ends_here) {
+            unsigned long long t = pmask;
+            for (int k = 1; k < need; ++k) t &= t - 1;
+            const int q = __ffsll((long long)t) - 1;
+            consumed = q + 1 + (int)((slow_mask >> q) & 1ull);
+          }
+          const u128 ns = lane_state(st, consumed);
+          if (lane == 0) { st_x[0] = ns.lo; st_x[1] = ns.hi; }
+        }
+      }
+      __syncthreads();
+      s.lo = st_x[0]; s.hi = st_x[1];
+      rank = new_rank;
     }
   }
 };

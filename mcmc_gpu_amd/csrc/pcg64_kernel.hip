@@ -12,14 +12,26 @@
 #include "ziggurat_tables.h"
 #include <math.h>
 
-namespace gsm {
+#ifndef GSM_PCG_DRAW_WAVES
+#define GSM_PCG_DRAW_WAVES 4
+#endif
 
-__global__ __launch_bounds__(64) void pcg64_draw_kernel(const PcgDrawArgs a) {
-  __shared__ uint64_t jump[4 * pcg::kJump];
+namespace gsm {
+static_assert(kPcgJumpWords == 4 * pcg::kJump && 64 * GSM_PCG_DRAW_WAVES <= pcg::kJump, "jump table size");
+
+// kDrawWaves wavefronts per chain: the scalar draws of a step are made by all of them redundantly (uniform code, same state
+// everywhere), the planes of normals by Stream::normals_mw -- one 64-draw window per wavefront and pass, speculating that the
+// windows before it are consumed whole.  One wavefront per chain (the first version: 0.15 ms per step of 1024 chains) leaves a
+// SIMD with a single latency-bound wave; four per chain fill the issue slots.
+constexpr int kDrawWaves = GSM_PCG_DRAW_WAVES;
+__global__ __launch_bounds__(64 * kDrawWaves) void pcg64_draw_kernel(const PcgDrawArgs a) {
+  constexpr int NW = kDrawWaves;
+  __shared__ uint64_t jump[4 * 64 * NW];
   __shared__ uint64_t zig[kZigTabWords];
-  const int lane = threadIdx.x, chain = blockIdx.x;
-  for (int i = lane; i < 4 * pcg::kJump; i += 64) jump[i] = a.jump[i];
-  for (int i = lane; i < kZigTabWords; i += 64) zig[i] = a.zig[i];
+  __shared__ uint64_t xch[NW + 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), chain = blockIdx.x;
+  for (int i = tid; i < 4 * 64 * NW; i += 64 * NW) jump[i] = a.jump[i];
+  for (int i = tid; i < kZigTabWords; i += 64 * NW) zig[i] = a.zig[i];
   __syncthreads();
   pcg::Stream R, C;
   uint64_t* rs = a.rf_state + 6 * (size_t)chain;
@@ -27,9 +39,10 @@ __global__ __launch_bounds__(64) void pcg64_draw_kernel(const PcgDrawArgs a) {
   R.s = pcg::u128{rs[0], rs[1]}; R.inc = pcg::u128{rs[2], rs[3]}; R.has32 = (uint32_t)rs[4]; R.cached = (uint32_t)rs[5];
   C.s = pcg::u128{cs[0], cs[1]}; C.inc = pcg::u128{cs[2], cs[3]}; C.has32 = (uint32_t)cs[4]; C.cached = (uint32_t)cs[5];
   R.jump = C.jump = jump; R.zig = C.zig = zig;
-  // this lane's jump constants of the RandField stream: lane + 1 draws ahead
-  const pcg::u128 A_l{jump[4 * lane], jump[4 * lane + 1]};
-  const pcg::u128 C_l = pcg::mul128(pcg::u128{jump[4 * lane + 2], jump[4 * lane + 3]}, R.inc);
+  // this lane's jump constants of the RandField stream: 64 wave + lane + 1 draws ahead
+  const int ahead = 64 * wave + lane;
+  const pcg::u128 A_l{jump[4 * ahead], jump[4 * ahead + 1]};
+  const pcg::u128 C_l = pcg::mul128(pcg::u128{jump[4 * ahead + 2], jump[4 * ahead + 3]}, R.inc);
   const gsm_rf_params& P = a.rf;
   for (int s = 0; s < a.n_steps; ++s) {
     const int64_t rec = (int64_t)chain * a.n_steps + s;
@@ -45,31 +58,32 @@ __global__ __launch_bounds__(64) void pcg64_draw_kernel(const PcgDrawArgs a) {
     for (int pl = 0; pl < 3; ++pl) {
       double* dst = (pl == 0) ? a.noise_re + rec * a.field_stride : (pl == 1) ? a.noise_im + rec * a.field_stride
                                                                               : (a.nugget ? a.nugget + rec * a.field_stride : nullptr);
-      R.normals(B, 0.0, (pl == 2) ? sqrt(nug) : 1.0, dst, lane, A_l, C_l);
+      if (NW == 1) R.normals(B, 0.0, (pl == 2) ? sqrt(nug) : 1.0, dst, lane, A_l, C_l);
+      else R.template normals_mw<NW>(B, 0.0, (pl == 2) ? sqrt(nug) : 1.0, dst, lane, wave, A_l, C_l, xch);
     }
     int ix = 0, iy = 0;
     for (int tries = 0;; ++tries) {
       ix = (int)C.bounded((uint32_t)a.H);
       iy = (int)C.bounded((uint32_t)a.W);
       if (!a.region_mask || a.region_mask[ix * a.W + iy] == 1) break;
-      if (tries > (1 << 20)) { if (lane == 0) atomicOr(a.err, 128); break; }
+      if (tries > (1 << 20)) { if (tid == 0) atomicOr(a.err, 128); break; }
     }
     const double uu = C.next_double();
-    if (lane == 0) {
+    if (tid == 0) {
       a.size_idx[rec] = si;
       a.centre[2 * rec] = ix; a.centre[2 * rec + 1] = iy;
       a.u[rec] = uu;
       a.rf_scalars[4 * rec] = scale; a.rf_scalars[4 * rec + 1] = nug; a.rf_scalars[4 * rec + 2] = rx; a.rf_scalars[4 * rec + 3] = ry;
     }
   }
-  if (lane == 0) {
+  if (tid == 0) {
     rs[0] = R.s.lo; rs[1] = R.s.hi; rs[4] = R.has32; rs[5] = R.cached;
     cs[0] = C.s.lo; cs[1] = C.s.hi; cs[4] = C.has32; cs[5] = C.cached;
   }
 }
 
 hipError_t launch_pcg64_draw(const PcgDrawArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(pcg64_draw_kernel, dim3(a.n_chains), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(pcg64_draw_kernel, dim3(a.n_chains), dim3(64 * kDrawWaves), 0, st, a);
   return hipGetLastError();
 }
 
@@ -78,12 +92,12 @@ hipError_t launch_pcg64_draw(const PcgDrawArgs& a, hipStream_t st) {
 // block centre with rejection on region_mask and block sizes; :128 rng.shuffle of the block's cells; :165 one rng.normal per cell
 // without conditioning data, in visiting order; :1797 rng.random()).  Same outputs as sgs_draw_kernel (Philox mode).
 __global__ __launch_bounds__(64) void sgs_draw_pcg64_kernel(const SgsDrawArgs a, uint64_t* states, const uint64_t* jump_g, const uint64_t* zig_g) {
-  __shared__ uint64_t jump[4 * pcg::kJump];
+  __shared__ uint64_t jump[4 * pcg::kJumpWave];
   __shared__ uint64_t zig[kZigTabWords];
   __shared__ int32_t order[1024];                // packed (row << 16 | col) of the block's cells, shuffled in place
   __shared__ double zt[1024];                    // the iteration's normals in drawing order
   const int lane = threadIdx.x, chain = blockIdx.x;
-  for (int i = lane; i < 4 * pcg::kJump; i += 64) jump[i] = jump_g[i];
+  for (int i = lane; i < 4 * pcg::kJumpWave; i += 64) jump[i] = jump_g[i];
   for (int i = lane; i < kZigTabWords; i += 64) zig[i] = zig_g[i];
   __syncthreads();
   pcg::Stream G;
