@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
         const cargs_t K = kargs();
         const ProposeArgs pa = load_cs(&K->P);
         relaunder();
-        dft_tt_write<kSW, kSUPW>(wave, ptid & 63, prop_geom(pa, s_bh, s_bw), lds, uc, us);
+        if (!(dbg & 2048)) dft_tt_write<kSW, kSUPW>(wave, ptid & 63, prop_geom(pa, s_bh, s_bw), lds, uc, us);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -208,8 +208,10 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
       relaunder();
       const int ln = ptid & 63;
       dft_stage2<kSW, kSMAXT, 2>(wave, ln, pa, q, pg, lds, t1 + 2 * kT1S, fe, fo);
-      double mean;
-      const double gain = standardise<kSW, kSMAXT>(wave, ln, q, pg, dc0, red2, fe, fo, mean);     // contains a barrier
+      double mean = 0.0;
+      double gain = 1.0;
+      if (dbg & 4096) { mean = 0.0; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+      else gain = standardise<kSW, kSMAXT>(wave, ln, q, pg, dc0, red2, fe, fo, mean);     // contains a barrier
       NoiseIn nz{nullptr, nullptr, nullptr};
       if (NOISE) {
         typedef const __attribute__((address_space(4))) FusedArgs* cfa_t;

@@ -5,7 +5,7 @@
 # wrong with any switch set.   scripts/pmc_ablate_strip.sh [steps]  -> gpurun_out/ablate_strip/summary.txt
 root=${GRAFT_REPO_ROOT:-$(pwd)}; out=$root/gpurun_out/ablate_strip; mkdir -p $out; export TMPDIR=/tmp; cd $root
 steps=${1:-256}
-for dbg in 0 128 384 896 1920 1952 1954 1958 1966; do
+for dbg in ${ABL_LIST:-0 128 384 896 1920 1952 1954 1958 1966}; do
   GSM_PROPOSE_DBG=$dbg rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $out/d$dbg -- python3 scripts/pmc_fused.py $steps > $out/d$dbg.log 2>&1
   python3 - <<PY
 import csv, glob, collections
