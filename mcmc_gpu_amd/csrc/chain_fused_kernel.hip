@@ -266,11 +266,10 @@ __global__ __launch_bounds__(kNT, 4) void chain_fused_kernel(const FusedArgs fa)
       dft_stage2<kNW, 1, true>(wave, ln, pa, q, pg, lds, fld, fe, fo);
       mask_prefetch<kNW, 1>(wave, ln, pa, q, pg, mreg);
       STAMP(11);
-      double mean;
-      const double gain = standardise<kNW, 1>(wave, ln, q, pg, dc0, red2, fe, fo, mean);     // contains a barrier
+      const double gain = standardise<kNW, 1>(wave, ln, q, pg, dc0, red2, fe, fo);     // contains a barrier
       STAMP(14);
       const bool with_nugget = pa.rf.nugget_max > 0.0;
-      emit_field<kNW, 1, true>(wave, ln, pa, q, pg, fe, fo, mreg, mean, gain, with_nugget, fld, [bw](int y, int x) { return y * bw + x; });
+      emit_field<kNW, 1, true>(wave, ln, pa, q, pg, fe, fo, mreg, gain, with_nugget, fld, [bw](int y, int x) { return y * bw + x; });
       if (with_nugget) {
         __syncthreads();
         relaunder();

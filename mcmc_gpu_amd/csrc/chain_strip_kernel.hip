@@ -208,10 +208,9 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
       relaunder();
       const int ln = ptid & 63;
       dft_stage2<kSW, kSMAXT, 2>(wave, ln, pa, q, pg, lds, t1 + 2 * kT1S, fe, fo);
-      double mean = 0.0;
       double gain = 1.0;
-      if (dbg & 4096) { mean = 0.0; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-      else gain = standardise<kSW, kSMAXT>(wave, ln, q, pg, dc0, red2, fe, fo, mean);     // contains a barrier
+      if (dbg & 4096) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else gain = standardise<kSW, kSMAXT>(wave, ln, q, pg, dc0, red2, fe, fo);     // contains a barrier
       NoiseIn nz{nullptr, nullptr, nullptr};
       if (NOISE) {
         typedef const __attribute__((address_space(4))) FusedArgs* cfa_t;
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
         if (nb) nz.nug = nb + noise0 + (int64_t)s * F->noise_stride;
       }
       const bool with_nugget = NOISE ? (nz.nug != nullptr) : (pa.rf.nugget_max > 0.0);
-      emit_field<kSW, kSMAXT, 2>(wave, ln, pa, q, pg, fe, fo, mreg, mean, gain, with_nugget, lds, [bw](int y, int x) { return (y + 1) * (bw + 2) + x + 1; }, m1);
+      emit_field<kSW, kSMAXT, 2>(wave, ln, pa, q, pg, fe, fo, mreg, gain, with_nugget, lds, [bw](int y, int x) { return (y + 1) * (bw + 2) + x + 1; }, m1);
       if (with_nugget) {
         __syncthreads();
         relaunder();

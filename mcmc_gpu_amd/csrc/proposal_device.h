@@ -563,49 +563,48 @@ __device__ __forceinline__ double tiles_sum(const double (&part)[MAXT], const in
 }
 
 // ---- standardise (MCMC.py:248) on the register-resident field -------------------------------------
-// lane holds, per (tile j, reg q): v1 = field[y][x] = E + O and, for 0 < x < hw, v2 = field[y][bw - x] = E - O.
-// On return fe / fo hold v1 / v2 (scaled by 1 / n) and the function value is the gain (scale / (sd + 1e-12)); `mean` out.
+// lane holds, per (tile j, reg q): E and O with n * field[y][x] = E + O and, for 0 < x < hw, n * field[y][bw - x] = E - O
+// (n = bh bw: the inverse DFT's 1 / n is still to be applied).  On return fe / fo hold n * (field - mean) for those two
+// cells (the DC coefficient dc is n * mean) and the function value is gain / n with gain = scale / (sd + 1e-12): the
+// standardised cell is fe * value.  The 1 / n is applied to the sum of squares and to the gain instead of to every
+// cell, which leaves four fp64 operations per cell here and one in emit_field, where scaled values cost five and two;
+// the deviations are still squared about the mean (fields whose spectrum is all but DC have mean^2 >> variance).
 template <int NW, int MAXT>
 __device__ __forceinline__ double standardise(const int w, const int lane, const PropScalars& sc, const PropGeom& g, const double dc,
-                                              double* red, v4f64 (&fe)[MAXT], v4f64 (&fo)[MAXT], double& mean) {
+                                              double* red, v4f64 (&fe)[MAXT], v4f64 (&fo)[MAXT]) {
   const int l15 = lane & 15, l4 = lane >> 4;
   const int bh = g.bh, hw = g.hw;
   const int n_mt2 = g.N1 >> 4, n_t2 = n_mt2 * (g.M1 >> 4);
   const int ncell = bh * g.bw;
   const double inv_n = 1.0 / (double)ncell;
   double part[MAXT];
-  mean = dc * inv_n;
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
     const int t = w + j * NW;
     const int nt = tile_div(t, g.q_mt2), mt = t - nt * n_mt2;
     const int x = 16 * nt + l15;
+    const bool okx = (w >= 0) && (t < n_t2) && (x <= hw);
+    const bool twox = okx && (x > 0) && (x < hw);
     double p = 0.0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int y = 16 * mt + l4 + 4 * q;
-      const bool ok = (w >= 0) && (t < n_t2) && (y < bh) && (x <= hw);
-      const bool two = ok && (x > 0) && (x < hw);
       const double e = fe[j][q], o = fo[j][q];
-      const double v1 = ok ? (e + o) * inv_n : 0.0;
-      const double v2 = two ? (e - o) * inv_n : 0.0;
-      fe[j][q] = v1; fo[j][q] = v2;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int y = 16 * mt + l4 + 4 * q;
-      const bool ok = (w >= 0) && (t < n_t2) && (y < bh) && (x <= hw);
-      if (ok) { const double d = fe[j][q] - mean; p += d * d; }
-      if (ok && x > 0 && x < hw) { const double d = fo[j][q] - mean; p += d * d; }
+      const double d1 = (e + o) - dc, d2 = (e - o) - dc;
+      fe[j][q] = d1; fo[j][q] = d2;
+      const double s1 = d1 * d1, s2 = d2 * d2;
+      p += (okx && y < bh) ? s1 : 0.0;
+      p += (twox && y < bh) ? s2 : 0.0;
     }
     part[j] = p;
   }
-  const double sd = sqrt(tiles_sum<NW, MAXT>(part, n_t2, red, w, lane) * inv_n);
-  return sc.scale / (sd + 1e-12);
+  // sum of n^2 (field - mean)^2 -> variance: twice 1 / n for the scaling, once for the mean over the cells
+  const double sd = sqrt(tiles_sum<NW, MAXT>(part, n_t2, red, w, lane) * inv_n * inv_n * inv_n);
+  return sc.scale / (sd + 1e-12) * inv_n;
 }
 
 // ---- scale, nugget (MCMC.py:251), edge mask (MCMC.py:778), store ------------------------------
-// out = (t + n * sqrt(nug)) * mask with t = (field - mean) * gain.  Without a nugget the finished value is stored
+// out = (t + n * sqrt(nug)) * mask with t = fe * gain, fe and gain as standardise leaves them.  Without a nugget the finished value is stored
 // directly; with one, t is stored first and nugget_pass adds the nugget normals and applies the mask -- the same
 // operations in the same order.  Cell (y, x) goes to out[omap(y, x)], or nowhere if omap returns a negative index.
 // MASKMODE: where the edge mask of a cell comes from -- 0 the packed table in global memory, 1 `mreg` (mask_prefetch), 2 a table
@@ -613,7 +612,7 @@ __device__ __forceinline__ double standardise(const int w, const int lane, const
 template <int NW, int MAXT, int MASKMODE, class OMap>
 __device__ __forceinline__ void emit_field(const int w, const int lane, const ProposeArgs& a, const PropScalars& sc, const PropGeom& g,
                                            const v4f64 (&fe)[MAXT], const v4f64 (&fo)[MAXT], const double (&mreg)[MAXT][8],
-                                           const double mean, const double gain, const bool with_nugget,
+                                           const double gain, const bool with_nugget,
                                            double* __restrict__ out, OMap omap, const double* m1d = nullptr) {
   if (w < 0) return;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -635,7 +634,7 @@ __device__ __forceinline__ void emit_field(const int w, const int lane, const Pr
           const int xx = half ? bw - x : x;
           const int o = y * bw + xx;
           const int oi = omap(y, xx);
-          const double v = ((half ? fo[j][q] : fe[j][q]) - mean) * gain;
+          const double v = (half ? fo[j][q] : fe[j][q]) * gain;
           double mk;
           if (MASKMODE == 2) mk = m1d[min(min(y, bh - 1 - y), min(xx, bw - 1 - xx))];
           else mk = (MASKMODE == 1) ? mreg[j][2 * q + half] : mask[o];
@@ -697,10 +696,9 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
   v4f64 fe[MAXT], fo[MAXT];
   dft_stage2<NW, MAXT, false>(wave, lane, a, sc, g, plds, nullptr, fe, fo);
   double mreg[MAXT][8];
-  double mean;
-  const double gain = standardise<NW, MAXT>(wave, lane, sc, g, dc, red, fe, fo, mean);
+  const double gain = standardise<NW, MAXT>(wave, lane, sc, g, dc, red, fe, fo);
   const bool with_nugget = NOISE_IN ? (noise.nug != nullptr) : (a.rf.nugget_max > 0.0);
-  emit_field<NW, MAXT, false>(wave, lane, a, sc, g, fe, fo, mreg, mean, gain, with_nugget, out, omap);
+  emit_field<NW, MAXT, false>(wave, lane, a, sc, g, fe, fo, mreg, gain, with_nugget, out, omap);
   if (with_nugget) {
     __syncthreads();
     nugget_pass<NT, NOISE_IN>(tid, a, sc, g, seed, step, noise, out, omap, mt);
