@@ -936,7 +936,7 @@ static int sgs_fill(gsm_handle h, SgsArgs& a, double* grids, const double* zcond
   // cells travel packed as (row << 16 | col) in an int32 and are unpacked with an arithmetic shift: rows up to 32767
   if (h->H < 2 || h->W < 2 || h->H > 32767 || h->W > 32767) return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": grid sides must be in [2, 32767]");
   // scratch: per (chain, slot) 48 x (value, weight) and a header; then ranks [n][1024] i32, rank_ok [n] i32
-  max_cells = (max_cells + 31) & ~31;                        // record stride: whole 32-cell chunks (sgs_sequence_kernel stages them by LDS-DMA)
+  max_cells = (max_cells + 63) & ~63;                        // record stride: whole 64-cell chunks (sgs_sequence_kernel: one cell per lane)
   const size_t n = (size_t)h->n_chains, cells_cap = n * (size_t)max_cells;
   if (h->sgs_rec_cells < cells_cap) {
     // a captured batch (gsm_sgs_iterate's hipGraph) holds the old scratch pointers: it must not be replayed

@@ -212,8 +212,9 @@ struct SgsArgs {
   int32_t* rank;           // [n_chains][1024]
   int32_t* rank_ok;        // [n_chains]
   SgsCellHdr* rec_hdr;     // [n_chains*max_cells]
-  double2* rec_vw;         // [n_chains*max_cells*48] (the neighbour's value, or a NaN-boxed block-local index where the neighbour
-                           //  is a cell simulated earlier in the block; its kriging weight)
+  double2* rec_vw;         // [n_chains*max_cells/64][48][64]: entry e of 64 consecutive cell slots side by side -- (the neighbour's value,
+                           //  or NaN-boxed (visiting slot << 16 | block-local index) where the neighbour is a cell simulated earlier in
+                           //  the block; its kriging weight)
 };
 hipError_t launch_sgs_blocks(const SgsArgs& a, int launch_cells, hipStream_t st);
 struct SgsDrawArgs {

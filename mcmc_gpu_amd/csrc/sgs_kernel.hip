@@ -412,12 +412,16 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
     if (lane < n) {
       gg = L.nb_g[lane];
       vw.y = w_l;
-      if (my_i >= r0 && my_i < r1 && my_j >= c0 && my_j < c1 && rank[(my_i - r0) * ww + (my_j - c0)] >= 0)
-        vw.x = __builtin_bit_cast(double, kSgsPendingTag | (uint64_t)((my_i - r0) * ww + (my_j - c0)));   // simulated earlier in this block
+      const bool inblk = my_i >= r0 && my_i < r1 && my_j >= c0 && my_j < c1;
+      const int nb_pos = (my_i - r0) * ww + (my_j - c0);
+      const int nb_slot = inblk ? rank[nb_pos] : -1;
+      if (nb_slot >= 0)          // simulated earlier in this block: its visiting slot and its block-local index (both < 1024)
+        vw.x = __builtin_bit_cast(double, kSgsPendingTag | ((uint64_t)nb_slot << 16) | (uint64_t)nb_pos);
       else
-        vw.x = (my_i >= r0 && my_i < r1 && my_j >= c0 && my_j < c1 && a.zcond) ? a.zcond[gg] : g[gg];
+        vw.x = (inblk && a.zcond) ? a.zcond[gg] : g[gg];
     }
-    a.rec_vw[rec * kSgsMaxPts + lane] = vw;
+    // entry `lane` of 64 consecutive cell slots lies side by side: sgs_sequence_kernel reads one cell per lane
+    a.rec_vw[((rec >> 6) * kSgsMaxPts + lane) * 64 + (rec & 63)] = vw;
     if (a.nbr_trace) a.nbr_trace[(size_t)(k_lo + slot) * kSgsMaxPts + lane] = gg;
   }
   if (lane == 0) {
@@ -431,15 +435,27 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// sgs_sequence_kernel: one wavefront per chain; the block's cells in visiting order
+// sgs_sequence_kernel: one wavefront per chain; the block's cells in visiting order, 64 at a time, one cell per lane.
+// The value pass is a sparse unit-lower-triangular solve (I - A) v = c with A[j][k] the coefficient of the earlier block cell k
+// in the estimate of cell j (w_jk + (1 - sum w_j) / n_j in ordinary kriging, w_jk in simple kriging) and c the part of the
+// estimate that is known already plus sd * z.  Per chunk of 64 cells:
+//   gather      every lane walks its own cell's neighbour list: values known before the block and values of cells of EARLIER chunks
+//               (final by now, in `overlay`) are summed; the coefficient of a neighbour in the SAME chunk goes to column `lane` of
+//               a 64 x 64 tile in LDS, and one bit of a 64-bit mask per lane says which of the tile's entries exist;
+//   sequence    cell kk of the chunk is final once the cells before it are: its value is broadcast (v_readlane) and every lane
+//               that lists it adds coefficient * value -- one fma on the chain's critical path per cell, where a wave reduction over
+//               the neighbour list per cell cost 650-800 cycles.
+// The records of the next chunk are requested before the sequence part of the current one and land in registers meanwhile.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kSeqChunk = 32;                                   // cells per staged chunk of records
-constexpr int kSeqVwDoubles = kSeqChunk * kSgsMaxPts * 2;       // 3072 = 24 x 128
-constexpr int kSeqHdrDoubles = kSeqChunk * 4;                   // 128
-static_assert(sizeof(SgsCellHdr) == 32 && kSeqVwDoubles % 128 == 0 && kSeqHdrDoubles % 128 == 0, "record chunks are whole 1 KiB pieces");
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const dev::v2i32 b = __builtin_bit_cast(dev::v2i32, v);
+  dev::v2i32 o;
+  o.x = __builtin_amdgcn_readlane(b.x, l); o.y = __builtin_amdgcn_readlane(b.y, l);
+  return __builtin_bit_cast(double, o);
+}
 __global__ __launch_bounds__(64) void sgs_sequence_kernel(const SgsArgs a) {
   __shared__ double overlay[kSgsMaxWin];
-  __shared__ __attribute__((aligned(16))) double stage[2][kSeqVwDoubles + kSeqHdrDoubles];
+  __shared__ double tile[64 * 64];                              // [cell of the chunk the value comes from][lane = cell that uses it]
   const int chain = blockIdx.x, lane = threadIdx.x;
   if (!a.rank_ok[chain]) return;
   const int H = a.H, W = a.W;
@@ -447,64 +463,74 @@ __global__ __launch_bounds__(64) void sgs_sequence_kernel(const SgsArgs a) {
   const int r0 = a.win[4 * chain], r1 = a.win[4 * chain + 1], c0 = a.win[4 * chain + 2], c1 = a.win[4 * chain + 3];
   const int wh = r1 - r0, ww = c1 - c0;
   const int k_lo = a.cell_off[chain], cnt = a.cell_cnt ? a.cell_cnt[chain] : a.cell_off[chain + 1] - k_lo;
-  // The records of a chunk of 32 cells travel global -> LDS by LDS-DMA (no registers, no wait in the cell loop) one chunk
-  // ahead; inside the loop a cell costs two LDS reads, one fused wave reduction and one LDS write.  (Register prefetching two
-  // cells ahead did not work: the compiler rotates the prefetched registers with moves at the loop latch and waits vmcnt(0)
-  // there -- a memory latency per cell, 0.65 us measured.)
-  const double* vw_src = (const double*)(a.rec_vw + (size_t)chain * a.max_cells * kSgsMaxPts);
-  const double* hdr_src = (const double*)(a.rec_hdr + (size_t)chain * a.max_cells);
-  auto request = [&](int chunk) {
-    double* dst = stage[chunk & 1];
-    dma_to_lds<1, 0>(vw_src + (size_t)chunk * kSeqVwDoubles, dst, kSeqVwDoubles, 0, lane);
-    dma_to_lds<1, 0>(hdr_src + (size_t)chunk * kSeqHdrDoubles, dst + kSeqVwDoubles, kSeqHdrDoubles, 0, lane);
+  const int np = a.num_points;
+  const size_t rec0 = (size_t)chain * a.max_cells;              // a multiple of 64 (sgs_fill)
+  const double2* __restrict__ vw_src = a.rec_vw + rec0 * kSgsMaxPts;
+  const double4* __restrict__ hdr_src = (const double4*)(a.rec_hdr + rec0);
+  static_assert(sizeof(SgsCellHdr) == 32, "a header is one double4");
+  double2 nx[kSgsMaxPts];
+  double4 hd = make_double4(0.0, 0.0, 0.0, 0.0);
+  auto request = [&](int kc) {                                  // chunk kc / 64: every load is 64 consecutive 16- or 32-byte items
+    hd = hdr_src[kc + lane];
+    const double2* src = vw_src + (size_t)(kc >> 6) * kSgsMaxPts * 64 + lane;
+#pragma unroll
+    for (int e = 0; e < kSgsMaxPts; ++e)
+      if (e < np) nx[e] = src[e * 64];
   };
   if (cnt > 0) request(0);
   for (int p = lane; p < wh * ww; p += 64) {
     const int gi = (r0 + p / ww) * W + c0 + p % ww;
     overlay[p] = a.zcond ? a.zcond[gi] : g[gi];
   }
-  // one wavefront: its LDS operations execute in order; waiting for the LDS counter orders a write against later reads
-  auto lds_order = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-  const int ln = min(lane, kSgsMaxPts - 1);
-  for (int kc = 0; kc < cnt; kc += kSeqChunk) {
-    const int chunk = kc / kSeqChunk;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // this chunk's records (and the overlay's loads) have landed
-    if (kc + kSeqChunk < cnt) request(chunk + 1);                     // the other buffer: its cells were finished a chunk ago
-    const double* st = stage[chunk & 1];
-    const int k_end = min(cnt, kc + kSeqChunk);
-    for (int k = kc; k < k_end; ++k) {
-      const int q = k - kc;
-      const double4 hraw = *(const double4*)(st + kSeqVwDoubles + 4 * q);
-      const double2 v0 = *(const double2*)(st + (q * kSgsMaxPts + ln) * 2);
-      lds_order();                    // both reads in flight together (else the neighbour read sinks below the header's branches: a second LDS round trip)
-      const uint64_t nop = __builtin_bit_cast(uint64_t, hraw.x);
-      const int n = __builtin_amdgcn_readfirstlane((int)(uint32_t)nop), op = __builtin_amdgcn_readfirstlane((int)(nop >> 32));
-      const double sdz = hraw.y, var = hraw.z, c1 = hraw.w;
-      if (n == -2) continue;                                              // cell outside its window: flagged by sgs_rank_kernel
-      if (n < 0) {                                                        // conditioned already: nothing drawn for it (MCMC.py:141)
-        if (a.trace && lane == 0) { a.trace[3 * (k_lo + k)] = -1.0; a.trace[3 * (k_lo + k) + 1] = overlay[op]; a.trace[3 * (k_lo + k) + 2] = 0.0; }
-        continue;
+  for (int kc = 0; kc < cnt; kc += 64) {
+    const int j = kc + lane;
+    const uint64_t nop = __builtin_bit_cast(uint64_t, hd.x);
+    const int n = (j < cnt) ? (int)(uint32_t)nop : -2, op = (int)(nop >> 32);
+    const double sdz = hd.y, var = hd.z, c1 = hd.w;
+    // ---- gather ----
+    double sv = 0.0, swv = 0.0;
+    uint64_t mask = 0;
+#pragma unroll
+    for (int e = 0; e < kSgsMaxPts; ++e) {
+      if (e < np) {                                             // wave-uniform
+        if (e < n) {
+          const uint64_t bits = __builtin_bit_cast(uint64_t, nx[e].x);
+          const double w = nx[e].y;
+          double v = nx[e].x;
+          bool known = true;
+          if ((bits & 0xFFFFFFFF00000000ull) == kSgsPendingTag) {
+            const int ks = (int)((uint32_t)bits >> 16) - kc;
+            if (ks >= 0) {                                      // a cell of this chunk (visited before this one: ks < lane)
+              tile[ks * 64 + lane] = (a.ktype == 0) ? w + c1 : w;
+              mask |= 1ull << ks;
+              known = false;
+            } else v = overlay[(uint32_t)bits & 0xFFFFu];
+          }
+          if (known) { sv += v; swv += w * v; }
+        }
       }
-      if (n == 0) {                                                       // error flagged by sgs_weights_kernel
-        if (lane == 0) overlay[op] = NAN;
-        lds_order();
-        continue;
+    }
+    // est = mean + sum w (v - mean) (_krige.py:42) as sum w v + sum v * (1 - sum w) / n with c1 = (1 - sum w) / n from the record;
+    // simple kriging (_krige.py:79): sum w v + global mean * (1 - sum w) = c1
+    double est = (n > 0) ? swv + (a.ktype == 0 ? sv * c1 : c1) : NAN;     // n == 0: error flagged by sgs_weights_kernel -> NaN
+    if (kc + 64 < cnt) request(kc + 64);
+    // ---- sequence ----
+    const int kend = min(64, cnt - kc);
+    for (int k8 = 0; k8 < kend; k8 += 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = tile[(k8 + u) * 64 + lane];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double vk = readlane_f64(est + sdz, k8 + u);       // final in lane k8 + u: every cell it lists came before
+        if ((mask >> (k8 + u)) & 1ull) est = __fma_rn(t[u], vk, est);
       }
-      const bool act = lane < n;
-      const uint64_t bits = __builtin_bit_cast(uint64_t, v0.x);
-      const bool pending = (bits & 0xFFFFFFFF00000000ull) == kSgsPendingTag;
-      const double v_l = act ? (pending ? overlay[(uint32_t)bits] : v0.x) : 0.0;
-      const double w_l = act ? v0.y : 0.0;
-      // est = mean + sum w (v - mean) (_krige.py:42) as sum w v + sum v * (1 - sum w) / n: the two sums reduce side by side (one
-      // DPP latency instead of two in a row on the chain's critical path), c1 = (1 - sum w) / n comes with the record
-      double sv = v_l, swv = w_l * v_l;
-      wave_sum2_f64(sv, swv);
-      const double est = swv + (a.ktype == 0 ? sv * c1 : c1);
-      if (lane == 0) {
-        overlay[op] = est + sdz;
-        if (a.trace) { a.trace[3 * (k_lo + k)] = (double)n; a.trace[3 * (k_lo + k) + 1] = est; a.trace[3 * (k_lo + k) + 2] = var; }
-      }
-      lds_order();
+    }
+    if (n == -1) {                                              // conditioned already: nothing drawn for it (MCMC.py:141)
+      if (a.trace) { a.trace[3 * (k_lo + j)] = -1.0; a.trace[3 * (k_lo + j) + 1] = overlay[op]; a.trace[3 * (k_lo + j) + 2] = 0.0; }
+    } else if (n >= 0) {
+      overlay[op] = est + sdz;
+      if (a.trace && n > 0) { a.trace[3 * (k_lo + j)] = (double)n; a.trace[3 * (k_lo + j) + 1] = est; a.trace[3 * (k_lo + j) + 2] = var; }
     }
   }
   __syncthreads();
