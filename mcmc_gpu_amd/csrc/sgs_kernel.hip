@@ -435,17 +435,20 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// sgs_sequence_kernel: one wavefront per chain; the block's cells in visiting order, 64 at a time, one cell per lane.
-// The value pass is a sparse unit-lower-triangular solve (I - A) v = c with A[j][k] the coefficient of the earlier block cell k
-// in the estimate of cell j (w_jk + (1 - sum w_j) / n_j in ordinary kriging, w_jk in simple kriging) and c the part of the
-// estimate that is known already plus sd * z.  Per chunk of 64 cells:
-//   gather      every lane walks its own cell's neighbour list: values known before the block and values of cells of EARLIER chunks
-//               (final by now, in `overlay`) are summed; the coefficient of a neighbour in the SAME chunk goes to column `lane` of
-//               a 64 x 64 tile in LDS, and one bit of a 64-bit mask per lane says which of the tile's entries exist;
-//   sequence    cell kk of the chunk is final once the cells before it are: its value is broadcast (v_readlane) and every lane
-//               that lists it adds coefficient * value -- one fma on the chain's critical path per cell, where a wave reduction over
-//               the neighbour list per cell cost 650-800 cycles.
-// The records of the next chunk are requested before the sequence part of the current one and land in registers meanwhile.
+// sgs_sequence_kernel: one workgroup of four wavefronts per chain; the block's cells in visiting order, 64 at a time, one
+// cell per lane.  The value pass is a sparse unit-lower-triangular solve (I - A) v = c with A[j][k] the coefficient of the
+// earlier block cell k in the estimate of cell j (w_jk + (1 - sum w_j) / n_j in ordinary kriging, w_jk in simple kriging)
+// and c the part of the estimate that is known already plus sd * z.  Per chunk of 64 cells:
+//   gather      (all four waves, every fourth group of four list entries each) every lane walks its own cell's neighbour list:
+//               values known before the block and values of cells of EARLIER chunks (final by now, in `overlay`) are summed;
+//               the coefficient of a neighbour in the SAME chunk goes to column `lane` of a 64 x 64 tile in LDS, and one bit
+//               of a 64-bit mask per lane says which of the tile's entries exist;
+//   sequence    (wave 0) cell kk of the chunk is final once the cells before it are: its value is broadcast (v_readlane) and
+//               every lane that lists it adds coefficient * value -- two v_readlane and one fma on the chain's critical path
+//               per cell, where a wave reduction over the neighbour list per cell cost 650-800 cycles.
+// The records of the next chunk are requested (LDS-DMA) before the sequence part of the current one and land meanwhile.
+// A cell whose kriging system failed (n == 0, error flag raised by sgs_weights_kernel) gets NaN, and so does every later
+// cell of its chunk and every cell that lists one of those.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   const dev::v2i32 b = __builtin_bit_cast(dev::v2i32, v);
@@ -453,95 +456,113 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   o.x = __builtin_amdgcn_readlane(b.x, l); o.y = __builtin_amdgcn_readlane(b.y, l);
   return __builtin_bit_cast(double, o);
 }
-__global__ __launch_bounds__(64) void sgs_sequence_kernel(const SgsArgs a) {
+constexpr int kSeqWaves = 4;
+__global__ __launch_bounds__(64 * kSeqWaves) void sgs_sequence_kernel(const SgsArgs a) {
   __shared__ double overlay[kSgsMaxWin];
-  __shared__ double tile[64 * 64];                              // [cell of the chunk the value comes from][lane = cell that uses it]
-  const int chain = blockIdx.x, lane = threadIdx.x;
+  __shared__ double tile[65 * 64];                              // [cell of the chunk the value comes from][lane = cell that uses it]; row 64 takes the writes of absent entries
+  __shared__ __attribute__((aligned(16))) double2 stage[kSgsMaxPts * 64];      // a chunk's neighbour records, [entry][cell]
+  __shared__ double2 part[kSeqWaves][64];                       // per wave and cell: (sum v, sum w v) over the wave's share of the list
+  __shared__ uint64_t mpart[kSeqWaves][64];
+  const int chain = blockIdx.x, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (!a.rank_ok[chain]) return;
   const int H = a.H, W = a.W;
   double* __restrict__ g = a.grid + (size_t)chain * H * W;
   const int r0 = a.win[4 * chain], r1 = a.win[4 * chain + 1], c0 = a.win[4 * chain + 2], c1 = a.win[4 * chain + 3];
   const int wh = r1 - r0, ww = c1 - c0;
   const int k_lo = a.cell_off[chain], cnt = a.cell_cnt ? a.cell_cnt[chain] : a.cell_off[chain + 1] - k_lo;
-  const int np = a.num_points;
+  const int np4 = (a.num_points + 3) & ~3, np8 = (a.num_points + 7) & ~7;
   const size_t rec0 = (size_t)chain * a.max_cells;              // a multiple of 64 (sgs_fill)
-  const double2* __restrict__ vw_src = a.rec_vw + rec0 * kSgsMaxPts;
+  const double* __restrict__ vw_src = (const double*)(a.rec_vw + rec0 * kSgsMaxPts);
   const double4* __restrict__ hdr_src = (const double4*)(a.rec_hdr + rec0);
   static_assert(sizeof(SgsCellHdr) == 32, "a header is one double4");
-  double2 nx[kSgsMaxPts];
   double4 hd = make_double4(0.0, 0.0, 0.0, 0.0);
-  auto request = [&](int kc) {                                  // chunk kc / 64: every load is 64 consecutive 16- or 32-byte items
+  // The records of a chunk travel global -> LDS by LDS-DMA (no registers; whole 1 KiB pieces = one entry of 64 cells, piece c by
+  // wave c mod 4); the headers (one per lane, the same in every wave) come through registers.
+  auto request = [&](int kc) {
     hd = hdr_src[kc + lane];
-    const double2* src = vw_src + (size_t)(kc >> 6) * kSgsMaxPts * 64 + lane;
-#pragma unroll
-    for (int e = 0; e < kSgsMaxPts; ++e)
-      if (e < np) nx[e] = src[e * 64];
+    dma_to_lds<kSeqWaves, 0>(vw_src + (size_t)(kc >> 6) * kSgsMaxPts * 128, (double*)stage, np8 * 128, wave, lane);
   };
   if (cnt > 0) request(0);
-  for (int p = lane; p < wh * ww; p += 64) {
+  for (int p = threadIdx.x; p < wh * ww; p += 64 * kSeqWaves) {
     const int gi = (r0 + p / ww) * W + c0 + p % ww;
     overlay[p] = a.zcond ? a.zcond[gi] : g[gi];
   }
   for (int kc = 0; kc < cnt; kc += 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of the chunk's records and its headers have landed
+    __syncthreads();                                            // ... and everybody's; the overlay holds every cell of the chunks before
     const int j = kc + lane;
     const uint64_t nop = __builtin_bit_cast(uint64_t, hd.x);
     const int n = (j < cnt) ? (int)(uint32_t)nop : -2, op = (int)(nop >> 32);
     const double sdz = hd.y, var = hd.z, c1 = hd.w;
-    // ---- gather ----
+    // ---- gather ----  (no branches; by groups of four entries: the group's LDS reads first, then its sums and tile entries)
     double sv = 0.0, swv = 0.0;
     uint64_t mask = 0;
+    for (int e0 = 4 * wave; e0 < np4; e0 += 4 * kSeqWaves) {
+      double2 r[4];
+      double ov[4];
 #pragma unroll
-    for (int e = 0; e < kSgsMaxPts; ++e) {
-      if (e < np) {                                             // wave-uniform
-        if (e < n) {
-          const uint64_t bits = __builtin_bit_cast(uint64_t, nx[e].x);
-          const double w = nx[e].y;
-          double v = nx[e].x;
-          bool known = true;
-          if ((bits & 0xFFFFFFFF00000000ull) == kSgsPendingTag) {
-            const int ks = (int)((uint32_t)bits >> 16) - kc;
-            if (ks >= 0) {                                      // a cell of this chunk (visited before this one: ks < lane)
-              tile[ks * 64 + lane] = (a.ktype == 0) ? w + c1 : w;
-              mask |= 1ull << ks;
-              known = false;
-            } else v = overlay[(uint32_t)bits & 0xFFFFu];
-          }
-          if (known) { sv += v; swv += w * v; }
-        }
+      for (int u = 0; u < 4; ++u) r[u] = stage[(e0 + u) * 64 + lane];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint64_t bits = __builtin_bit_cast(uint64_t, r[u].x);
+        const bool early = (e0 + u < n) && ((bits & 0xFFFFFFFF00000000ull) == kSgsPendingTag) && ((int)((uint32_t)bits >> 16) < kc);
+        ov[u] = overlay[early ? ((uint32_t)bits & 0xFFFFu) : 0u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u;
+        const uint64_t bits = __builtin_bit_cast(uint64_t, r[u].x);
+        const double w = r[u].y;
+        const bool pend = (bits & 0xFFFFFFFF00000000ull) == kSgsPendingTag;
+        const int ks = (int)((uint32_t)bits >> 16) - kc;         // >= 0: a cell of this chunk (visited before this one: ks < lane)
+        const bool here = (e < n) && pend && ks >= 0, known = (e < n) && !(pend && ks >= 0);
+        const double v = pend ? ov[u] : r[u].x;
+        const double wv = w * v;
+        sv += known ? v : 0.0;
+        swv += known ? wv : 0.0;
+        tile[here ? ks * 64 + lane : 64 * 64 + lane] = (a.ktype == 0) ? w + c1 : w;       // row 64: nobody reads it
+        mask |= here ? (1ull << ks) : 0ull;
       }
     }
+    part[wave][lane] = make_double2(sv, swv);
+    mpart[wave][lane] = mask;
+    __syncthreads();                                            // the records have been read: the next chunk's may overwrite them
+    if (kc + 64 < cnt) request(kc + 64);
+    if (wave != 0) continue;
+    // ---- sequence (wave 0) ----
+    sv = 0.0; swv = 0.0; mask = 0;
+#pragma unroll
+    for (int w = 0; w < kSeqWaves; ++w) { const double2 q = part[w][lane]; sv += q.x; swv += q.y; mask |= mpart[w][lane]; }
     // est = mean + sum w (v - mean) (_krige.py:42) as sum w v + sum v * (1 - sum w) / n with c1 = (1 - sum w) / n from the record;
     // simple kriging (_krige.py:79): sum w v + global mean * (1 - sum w) = c1
-    double est = (n > 0) ? swv + (a.ktype == 0 ? sv * c1 : c1) : NAN;     // n == 0: error flagged by sgs_weights_kernel -> NaN
-    if (kc + 64 < cnt) request(kc + 64);
-    // ---- sequence ----
+    // val = est + sd z is what travels: value of the cell = (known part of the estimate + sd z) + the chunk's own cells' part
+    // n == 0: error flagged by sgs_weights_kernel -> NaN; a lane without a cell to simulate must hold a finite number (0 * NaN)
+    double val = (n > 0) ? (swv + (a.ktype == 0 ? sv * c1 : c1)) + sdz : (n == 0 ? NAN : 0.0);
     const int kend = min(64, cnt - kc);
     for (int k8 = 0; k8 < kend; k8 += 8) {
       double t[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = tile[(k8 + u) * 64 + lane];
+      for (int u = 0; u < 8; ++u) { const double tt = tile[(k8 + u) * 64 + lane]; t[u] = ((mask >> (k8 + u)) & 1ull) ? tt : 0.0; }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const double vk = readlane_f64(est + sdz, k8 + u);       // final in lane k8 + u: every cell it lists came before
-        if ((mask >> (k8 + u)) & 1ull) est = __fma_rn(t[u], vk, est);
-      }
+      for (int u = 0; u < 8; ++u) val = __fma_rn(t[u], readlane_f64(val, k8 + u), val);     // lane k8 + u is final: every cell it lists came before
     }
     if (n == -1) {                                              // conditioned already: nothing drawn for it (MCMC.py:141)
       if (a.trace) { a.trace[3 * (k_lo + j)] = -1.0; a.trace[3 * (k_lo + j) + 1] = overlay[op]; a.trace[3 * (k_lo + j) + 2] = 0.0; }
     } else if (n >= 0) {
-      overlay[op] = est + sdz;
-      if (a.trace && n > 0) { a.trace[3 * (k_lo + j)] = (double)n; a.trace[3 * (k_lo + j) + 1] = est; a.trace[3 * (k_lo + j) + 2] = var; }
+      overlay[op] = val;
+      if (a.trace && n > 0) { a.trace[3 * (k_lo + j)] = (double)n; a.trace[3 * (k_lo + j) + 1] = val - sdz; a.trace[3 * (k_lo + j) + 2] = var; }
     }
   }
   __syncthreads();
-  for (int p = lane; p < wh * ww; p += 64) g[(size_t)(r0 + p / ww) * W + c0 + p % ww] = overlay[p];
+  for (int p = threadIdx.x; p < wh * ww; p += 64 * kSeqWaves) g[(size_t)(r0 + p / ww) * W + c0 + p % ww] = overlay[p];
 }
 
 hipError_t launch_sgs_blocks(const SgsArgs& a, int launch_cells, hipStream_t st) {
   if (a.hw < 1 || a.num_points < 8 || a.num_points > kSgsMaxPts || a.H < 2 || a.W < 2 || a.H > 32767 || a.W > 32767) return hipErrorInvalidValue;
   hipLaunchKernelGGL(sgs_rank_kernel, dim3(a.n_chains), dim3(256), 0, st, a);
   if (launch_cells > 0) hipLaunchKernelGGL(sgs_weights_kernel, dim3(launch_cells, a.n_chains), dim3(64), 0, st, a);
-  hipLaunchKernelGGL(sgs_sequence_kernel, dim3(a.n_chains), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(sgs_sequence_kernel, dim3(a.n_chains), dim3(64 * kSeqWaves), 0, st, a);
   return hipGetLastError();
 }
 
