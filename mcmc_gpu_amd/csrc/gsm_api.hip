@@ -32,7 +32,7 @@ struct gsm_context {
   int tables_len = 0, tab_max = 0;
   double* d_k2 = nullptr;        // per-size k^2 tables of the spectral amplitude (depend on rf.resolution)
   double* d_mathtab = nullptr;   // log / sincos table of the coefficient phase (math_tables.h)
-  double* d_sgs_part_sum = nullptr; int32_t* d_sgs_part_bad = nullptr; size_t sgs_part_cap = 0;   // gsm_sgs_loss partial sums
+  double* d_sgs_part_sum = nullptr; int32_t* d_sgs_part_bad = nullptr; int32_t* d_sgs_ticket = nullptr; size_t sgs_part_cap = 0;   // gsm_sgs_loss partial sums
   // gsm_sgs_blocks scratch: visiting ranks + one record per (chain, cell slot), see SgsArgs
   void* d_sgs_rec = nullptr; size_t sgs_rec_cells = 0;
   // gsm_sgs_iterate: the captured launch sequence of one batch (hipGraph), keyed by the bytes of its gsm_sgs_batch + n_iters
@@ -143,7 +143,7 @@ extern "C" int gsm_destroy(gsm_handle h) {
   for (auto& p : h->d_scalars) if (p) hipFree(p);
   if (h->d_k2) hipFree(h->d_k2);
   if (h->d_mathtab) hipFree(h->d_mathtab);
-  if (h->d_sgs_part_sum) { hipFree(h->d_sgs_part_sum); hipFree(h->d_sgs_part_bad); }
+  if (h->d_sgs_part_sum) { hipFree(h->d_sgs_part_sum); hipFree(h->d_sgs_part_bad); hipFree(h->d_sgs_ticket); }
   if (h->d_sgs_rec) hipFree(h->d_sgs_rec);
   if (h->sgs_graph_exec) hipGraphExecDestroy(h->sgs_graph_exec);
   if (h->d_pcg_tab) hipFree(h->d_pcg_tab);
@@ -1077,21 +1077,29 @@ extern "C" int gsm_sgs_draw_pcg64(gsm_handle h, uint64_t* chain_state, int32_t n
   return GSM_OK;
 }
 
+// scratch of the loss kernels: a partial sum and bad-cell count per (chain, part), and per chain the ticket of sgs_loss_tail_kernel
+// (zero between launches: the kernel resets it)
+static int sgs_parts_ensure(gsm_handle h) {
+  const size_t need = (size_t)h->n_chains * sgs_loss_parts(h->S);
+  if (h->sgs_part_cap >= need) return GSM_OK;
+  if (h->sgs_graph_exec) { hipGraphExecDestroy(h->sgs_graph_exec); h->sgs_graph_exec = nullptr; }     // captured with the old scratch
+  h->sgs_graph_key.clear();
+  if (h->d_sgs_part_sum) { hipFree(h->d_sgs_part_sum); hipFree(h->d_sgs_part_bad); hipFree(h->d_sgs_ticket); h->d_sgs_part_sum = nullptr; h->d_sgs_part_bad = nullptr; h->d_sgs_ticket = nullptr; h->sgs_part_cap = 0; }
+  HIPCHK(h, hipMalloc(&h->d_sgs_part_sum, need * sizeof(double)));
+  HIPCHK(h, hipMalloc(&h->d_sgs_part_bad, need * sizeof(int32_t)));
+  HIPCHK(h, hipMalloc(&h->d_sgs_ticket, (size_t)h->n_chains * sizeof(int32_t)));
+  HIPCHK(h, hipMemset(h->d_sgs_ticket, 0, (size_t)h->n_chains * sizeof(int32_t)));
+  h->sgs_part_cap = need;
+  return GSM_OK;
+}
+
 extern "C" int gsm_sgs_loss(gsm_handle h, const double* beds, const double* trend, double* loss, int32_t* bad, void* stream) {
   if (!h) return GSM_E_ARG;
   if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_sgs_loss: call gsm_set_static first");
   if (h->f32_state) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_loss: fp64 beds only");
   if (!beds || !loss || !bad) return fail(h, GSM_E_ARG, "gsm_sgs_loss: NULL pointer");
   HIPCHK(h, hipSetDevice(h->device));
-  const size_t need = (size_t)h->n_chains * sgs_loss_parts(h->S);
-  if (h->sgs_part_cap < need) {
-    if (h->sgs_graph_exec) { hipGraphExecDestroy(h->sgs_graph_exec); h->sgs_graph_exec = nullptr; }     // captured with the old scratch
-    h->sgs_graph_key.clear();
-    if (h->d_sgs_part_sum) { hipFree(h->d_sgs_part_sum); hipFree(h->d_sgs_part_bad); h->d_sgs_part_sum = nullptr; h->d_sgs_part_bad = nullptr; h->sgs_part_cap = 0; }
-    HIPCHK(h, hipMalloc(&h->d_sgs_part_sum, need * sizeof(double)));
-    HIPCHK(h, hipMalloc(&h->d_sgs_part_bad, need * sizeof(int32_t)));
-    h->sgs_part_cap = need;
-  }
+  if (int rc = sgs_parts_ensure(h)) return rc;
   HIPCHK(h, launch_sgs_loss(h->S, h->n_chains, beds, trend, loss, bad, h->d_sgs_part_sum, h->d_sgs_part_bad, (hipStream_t)stream));
   return GSM_OK;
 }
@@ -1180,12 +1188,13 @@ static int sgs_issue(gsm_handle h, const gsm_sgs_batch* b, int32_t n_iters, void
       continue;
     }
     if (qt && (rc = gsm_qt_transform(h, b->qt_quantiles, b->qt_references, b->qt_n, b->next, b->proposed, map, 1, st))) return rc;  // MCMC.py:1777
-    if ((rc = gsm_sgs_loss(h, qt ? b->proposed : b->next, b->trend, b->loss, b->bad, st))) return rc;
-    if ((rc = gsm_sgs_decide(h, b->loss, b->bad, u, b->loss_prev, b->accept, b->loss_rec ? b->loss_rec + j : nullptr,
-                             b->acc_rec ? b->acc_rec + j : nullptr, n_iters, st))) return rc;
-    rc = qt ? gsm_sgs_commit_map(h, b->cur, b->proposed, b->resampled, win, b->accept, st)
-            : gsm_sgs_commit(h, b->cur, b->next, b->resampled, win, b->accept, st);
-    if (rc) return rc;
+    // loss of the proposal, decision and commit (gsm_sgs_loss, gsm_sgs_decide, gsm_sgs_commit_map / gsm_sgs_commit) in one launch
+    if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_sgs_iterate: call gsm_set_static first");
+    if (h->f32_state) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_iterate: fp64 beds only");
+    if ((rc = sgs_parts_ensure(h))) return rc;
+    HIPCHK(h, launch_sgs_loss_tail(h->S, h->n_chains, b->trend, h->d_sgs_part_sum, h->d_sgs_part_bad, h->d_sgs_ticket, b->loss, b->bad, u,
+                                   b->loss_prev, b->accept, b->loss_rec ? b->loss_rec + j : nullptr, b->acc_rec ? b->acc_rec + j : nullptr,
+                                   n_iters, qt ? 1 : 2, b->cur, qt ? b->proposed : b->next, b->resampled, win, (hipStream_t)st));
   }
   return GSM_OK;
 }

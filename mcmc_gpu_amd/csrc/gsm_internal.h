@@ -232,6 +232,10 @@ hipError_t launch_sgs_draw(const SgsDrawArgs& a, hipStream_t st);
 int sgs_loss_parts(const StaticFields& S);      // workgroups per chain of the loss kernel; scratch = n_chains * parts doubles + ints
 hipError_t launch_sgs_loss(const StaticFields& S, int n_chains, const double* beds, const double* trend, double* loss, int32_t* bad,
                            double* part_sum, int32_t* part_bad, hipStream_t st);
+hipError_t launch_sgs_loss_tail(const StaticFields& S, int n_chains, const double* trend, double* part_sum, int32_t* part_bad, int32_t* ticket,
+                                double* loss, int32_t* bad, const double* u, double* loss_prev, uint8_t* accept, double* loss_rec,
+                                uint8_t* acc_rec, int64_t rec_stride, int mode, double* cur, double* beds, uint32_t* resampled,
+                                const int32_t* win, hipStream_t st);
 hipError_t launch_sgs_state_init(const StaticFields& S, int n_chains, const double* beds, const double* trend, double* energy, double* state,
                                  hipStream_t st);
 hipError_t launch_sgs_finish(const StaticFields& S, int n_chains, double* cur, double* next, const double* trend, double* energy, double* state,

@@ -574,14 +574,9 @@ hipError_t launch_sgs_blocks(const SgsArgs& a, int launch_cells, hipStream_t st)
 // ---------------------------------------------------------------------------------------------------------------------
 // Several workgroups per chain (a chain's grid is split into `parts` contiguous ranges of cells), then one thread per chain
 // adds the parts in order: with one workgroup per chain a 256 x 256 grid kept 16 CUs busy for 0.19 ms per iteration.
-__global__ __launch_bounds__(256) void sgs_loss_kernel(const StaticFields S, const double* beds, const double* trend, int parts,
-                                                       double* part_sum, int32_t* part_bad) {
-  __shared__ double red[8];
-  __shared__ int redb[4];
-  const int chain = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
-  const int plane = S.H * S.W;
-  const int per = (plane + parts - 1) / parts, g_lo = part * per, g_hi = min(plane, g_lo + per);
-  const double* bed = beds + (size_t)chain * plane;
+// one part of a chain's map by the 256 threads of a workgroup; thread 0 returns the part's sum and bad-cell count
+__device__ __forceinline__ void sgs_loss_part(const StaticFields& S, const double* bed, const double* trend, int g_lo, int g_hi, int tid,
+                                              double* red, int* redb, double& sum_out, int& bad_out) {
   auto bed_at = [&](int rr, int cc) { const int q = rr * S.W + cc; return trend ? bed[q] + trend[q] : bed[q]; };
   double hi = 0.0, lo = 0.0;
   int nbad = 0;
@@ -602,10 +597,19 @@ __global__ __launch_bounds__(256) void sgs_loss_kernel(const StaticFields S, con
   for (int off = 32; off > 0; off >>= 1) { t += __shfl_xor(t, off, 64); nbad += __shfl_xor(nbad, off, 64); }
   if ((tid & 63) == 0) { red[tid >> 6] = t; redb[tid >> 6] = nbad; }
   __syncthreads();
-  if (tid == 0) {
-    part_sum[chain * parts + part] = ((red[0] + red[1]) + red[2]) + red[3];
-    part_bad[chain * parts + part] = redb[0] + redb[1] + redb[2] + redb[3];
-  }
+  sum_out = ((red[0] + red[1]) + red[2]) + red[3];
+  bad_out = redb[0] + redb[1] + redb[2] + redb[3];
+}
+__global__ __launch_bounds__(256) void sgs_loss_kernel(const StaticFields S, const double* beds, const double* trend, int parts,
+                                                       double* part_sum, int32_t* part_bad) {
+  __shared__ double red[8];
+  __shared__ int redb[4];
+  const int chain = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+  const int plane = S.H * S.W;
+  const int per = (plane + parts - 1) / parts, g_lo = part * per, g_hi = min(plane, g_lo + per);
+  double t; int nb;
+  sgs_loss_part(S, beds + (size_t)chain * plane, trend, g_lo, g_hi, tid, red, redb, t, nb);
+  if (tid == 0) { part_sum[chain * parts + part] = t; part_bad[chain * parts + part] = nb; }
 }
 __global__ __launch_bounds__(64) void sgs_loss_finish_kernel(int n_chains, int parts, double two_sigma2, const double* __restrict__ part_sum,
                                                              const int32_t* __restrict__ part_bad, double* __restrict__ loss, int32_t* __restrict__ bad) {
@@ -912,6 +916,87 @@ __global__ __launch_bounds__(64) void sgs_commit_kernel(int H, int W, double* cu
 hipError_t launch_sgs_commit(int H, int W, int n_chains, double* cur, double* next, uint32_t* resampled, const int32_t* win,
                              const uint8_t* accept, hipStream_t st) {
   hipLaunchKernelGGL(sgs_commit_kernel, dim3(n_chains), dim3(64), 0, st, H, W, cur, next, resampled, win, accept);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The end of an iteration of gsm_sgs_iterate in ONE launch: loss parts as sgs_loss_kernel; the workgroup of a chain that
+// finishes last (a ticket per chain, device-scope fences) adds the parts in order (= sgs_loss_finish_kernel), takes the
+// decision (= sgs_decide_kernel) and commits (mode 1 = sgs_commit_map_kernel: `beds` is the proposed plane; mode 2 =
+// sgs_commit_kernel: `beds` is `next`).  Four launches of ~5 us each at 4 chains become one.  The ticket resets itself.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SgsTailArgs {
+  const double* trend; int parts; double* part_sum; int32_t* part_bad; int32_t* ticket;
+  double* loss; int32_t* bad; const double* u; double* loss_prev; uint8_t* accept; double* loss_rec; uint8_t* acc_rec; int64_t rec_stride;
+  int mode; double* cur; double* beds; uint32_t* resampled; const int32_t* win;
+};
+__global__ __launch_bounds__(256) void sgs_loss_tail_kernel(const StaticFields S, const SgsTailArgs a) {
+  __shared__ double red[8];
+  __shared__ int redb[4];
+  __shared__ int s_last, s_acc;
+  const int chain = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+  const int H = S.H, W = S.W, plane = H * W, parts = a.parts;
+  const int per = (plane + parts - 1) / parts, g_lo = part * per, g_hi = min(plane, g_lo + per);
+  const size_t base = (size_t)chain * plane;
+  double t; int nb;
+  sgs_loss_part(S, a.beds + base, a.trend, g_lo, g_hi, tid, red, redb, t, nb);
+  if (tid == 0) {
+    __hip_atomic_store(&a.part_sum[chain * parts + part], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&a.part_bad[chain * parts + part], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ticket = __hip_atomic_fetch_add(&a.ticket[chain], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == parts - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (tid == 0) {
+    double s = 0.0;
+    int nbad = 0;
+    for (int p = 0; p < parts; ++p) {
+      s += __hip_atomic_load(&a.part_sum[chain * parts + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      nbad += __hip_atomic_load(&a.part_bad[chain * parts + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    a.ticket[chain] = 0;
+    const double loss = s / S.two_sigma2;
+    a.loss[chain] = loss; a.bad[chain] = nbad;
+    const double ln = (nbad > 0) ? INFINITY : loss;
+    const double lp = a.loss_prev[chain];
+    bool acc = true;
+    if (!(lp > ln)) {
+      const double p = exp(lp - ln);
+      acc = a.u[chain] <= ((p > 1.0) ? 1.0 : p);        // p NaN: the comparison is false (numpy.minimum propagates the NaN)
+    }
+    const double l = acc ? ln : lp;
+    a.loss_prev[chain] = l;
+    a.accept[chain] = acc ? 1 : 0;
+    if (a.loss_rec) a.loss_rec[(int64_t)chain * a.rec_stride] = l;
+    if (a.acc_rec) a.acc_rec[(int64_t)chain * a.rec_stride] = acc ? 1 : 0;
+    s_acc = acc ? 1 : 0;
+  }
+  __syncthreads();
+  const bool acc = s_acc != 0;
+  const int r0 = a.win[4 * chain], r1 = a.win[4 * chain + 1], c0 = a.win[4 * chain + 2], c1 = a.win[4 * chain + 3];
+  const int ww = c1 - c0, n = (r1 - r0) * ww;
+  if (a.mode == 1) {
+    if (!acc) return;
+    for (int p = tid; p < plane; p += 256) a.cur[base + p] = a.beds[base + p];
+    for (int p = tid; p < n; p += 256) a.resampled[base + (size_t)(r0 + p / ww) * W + c0 + p % ww] += 1u;
+  } else {
+    for (int p = tid; p < n; p += 256) {
+      const size_t q = base + (size_t)(r0 + p / ww) * W + c0 + p % ww;
+      if (acc) { a.cur[q] = a.beds[q]; a.resampled[q] += 1u; }
+      else a.beds[q] = a.cur[q];
+    }
+  }
+}
+hipError_t launch_sgs_loss_tail(const StaticFields& S, int n_chains, const double* trend, double* part_sum, int32_t* part_bad, int32_t* ticket,
+                                double* loss, int32_t* bad, const double* u, double* loss_prev, uint8_t* accept, double* loss_rec,
+                                uint8_t* acc_rec, int64_t rec_stride, int mode, double* cur, double* beds, uint32_t* resampled,
+                                const int32_t* win, hipStream_t st) {
+  SgsTailArgs a;
+  a.trend = trend; a.parts = sgs_loss_parts(S); a.part_sum = part_sum; a.part_bad = part_bad; a.ticket = ticket;
+  a.loss = loss; a.bad = bad; a.u = u; a.loss_prev = loss_prev; a.accept = accept; a.loss_rec = loss_rec; a.acc_rec = acc_rec;
+  a.rec_stride = rec_stride; a.mode = mode; a.cur = cur; a.beds = beds; a.resampled = resampled; a.win = win;
+  hipLaunchKernelGGL(sgs_loss_tail_kernel, dim3(n_chains, a.parts), dim3(256), 0, st, S, a);
   return hipGetLastError();
 }
 
