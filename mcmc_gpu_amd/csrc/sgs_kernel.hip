@@ -133,6 +133,7 @@ struct SgsSearchLds {
   int32_t list_g[8][kSgsListCap];
   int32_t len[8];
   int32_t cum[8];
+  int32_t arcs[8];                        // the arcs of a ring that can hold cells of an open sector
   uint32_t cert[8][kSgsCertMax / 2];      // candidates of a sector by certification ring: 16-bit counters, two per word (a ring holds
                                           // at most 8 x 127 cells).  The kernel's occupancy is bounded by this structure's size.
   int32_t nb_g[kSgsMaxPts];
@@ -161,6 +162,15 @@ __device__ __forceinline__ void sgs_prune_sector(SgsSearchLds& L, int s, int kee
   if (lane < n) { L.list_d[s][lane] = L.tmp_d[lane]; L.list_g[s][lane] = L.tmp_g[lane]; }
   if (lane == 0) L.len[s] = n;
   __syncthreads();
+}
+
+// cell `p` (0 <= p < R) of arc `g` (0..7) of the square ring of Chebyshev radius R around a cell, as (row, column) offsets: the ring's
+// 8 R cells in the order top row left to right, right column downwards, bottom row right to left, left column upwards; each side
+// is two arcs of R cells, the first starting at a corner (p = 0), the second at the cell on the axis
+__device__ __forceinline__ void ring_cell(int R, int g, int p, int& di, int& dj) {
+  const int side = g >> 1, e = ((g & 1) ? 0 : -R) + p;
+  di = (side == 0) ? -R : (side == 2) ? R : (side == 1) ? e : -e;
+  dj = (side == 1) ? R : (side == 3) ? -R : (side == 0) ? e : -e;
 }
 
 template <int K>
@@ -222,6 +232,20 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
   double radius = a.radius;
   int hw = a.hw;
   int n = 0;
+  // The sectors the cells strictly inside arc g can fall into (lane g < 8), whatever the ring: the directions of the arc's first and
+  // last inner cell on a huge ring bound them, and the sector number changes monotonically along a ring.
+  unsigned my_arcsec = 0;
+  {
+    constexpr int BIG = 1 << 20;
+    auto sec_of = [&](int gq, int p) { int di, dj; ring_cell(BIG, gq & 7, p, di, dj); return octant(-(double)di * sy, -(double)dj * sx); };
+    const int dirp = (((sec_of(2, 1) - sec_of(0, 1)) & 7) == 2) ? 1 : -1;
+    if (lane < 8) {
+      const int s_b = sec_of(lane, 1), s_e = sec_of(lane, BIG - 1);
+      const int steps = ((s_e - s_b) * dirp) & 7;
+      for (int i = 0; i < 8; ++i)
+        if (i <= steps) my_arcsec |= 1u << ((s_b + i * dirp) & 7);
+    }
+  }
   for (;;) {                                                     // radius widening (MCMC.py:150-156): usually one trip
     const int ilo = max(0, i0 - hw), ihi = min(H - 1, i0 + hw), jlo = max(0, j0 - hw), jhi = min(W - 1, j0 + hw);
     // cells towards smaller / larger row and column that the window holds
@@ -242,54 +266,85 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
     }
     unsigned done_mask = 0;                                      // wave-uniform: sectors complete or exhausted
     int R = 0;
+    bool long_list = false;
+    // one candidate cell per lane: everything is computed for every lane at clamped (always valid) indices; ONE predicate guards the insertion
+    auto probe = [&](int di, int dj, bool ok) {
+      const int i = i0 + di, j = j0 + dj;
+      ok = ok && i >= ilo && i <= ihi && j >= jlo && j <= jhi;
+      const int ic = min(max(i, ilo), ihi), jc = min(max(j, jlo), jhi);
+      const bool inwin = ic >= r0 && ic < r1 && jc >= c0 && jc < c1;
+      const int rk = rank[inwin ? (ic - r0) * ww + (jc - c0) : 0];
+      const double gv = g[ic * W + jc];
+      const double ddx = x0 - a.xs[jc], ddy = y0 - a.ys[ic];
+      const double d = sqrt(ddx * ddx + ddy * ddy);
+      const int s = octant(ddy, ddx);
+      // rk: -1 = conditioning data, < slot = simulated before this cell
+      const bool ins = ok && (inwin ? rk < slot : !isnan(gv)) && d < radius && !((done_mask >> s) & 1u);
+      if (ins) {
+        const int pos = atomicAdd(&L.len[s], 1);
+        long_list |= pos + 1 > kSgsListCap - 64;
+        L.list_d[s][pos] = d; L.list_g[s][pos] = i * W + j;
+        const double qf = d * inv_cert;
+        if (qf < (double)kSgsCertMax) { const int qi = (int)qf; atomicAdd(&L.cert[s][qi >> 1], 1u << (16 * (qi & 1))); }
+      }
+      __syncthreads();
+      // a list that could not take another full pass is cut back to the k8 nearest (nothing beyond them can be selected); the lane
+      // whose insertion took a list over that mark knows: the eight lengths are only looked at then
+      if (__ballot(long_list)) {
+        for (int s = 0; s < 8; ++s)
+          if (L.len[s] > kSgsListCap - 64) sgs_prune_sector(L, s, k8, lane);
+        long_list = false;
+      }
+    };
     while (R < r_max && done_mask != 0xFFu) {
-      // one pass = rings R+1 .. R_hi: the 7 x 7 window first (rings 1-3 = 48 cells), then ring by ring
-      const int R_lo = R + 1, R_hi = (R == 0) ? min(3, r_max) : R + 1;
-      int cells_in_pass, side_w = 0;
-      if (R == 0) { side_w = 2 * R_hi + 1; cells_in_pass = side_w * side_w; } else cells_in_pass = 8 * R_hi;
-      const float inv_side = 1.0f / (float)(2 * R_hi);
-      bool long_list = false;
-      for (int t0 = 0; t0 < cells_in_pass; t0 += 64) {
-        const int t = t0 + lane;
-        int di = 0, dj = 0;
-        bool ok = t < cells_in_pass;
-        if (R == 0) {
-          di = t / side_w - R_hi; dj = t % side_w - R_hi;
-          ok = ok && !(di == 0 && dj == 0);
-        } else {
+      // one pass = rings R+1 .. R_hi: the 7 x 7 window first (rings 1-3 = 48 cells); then whole rings while most sectors are open,
+      // and only the arcs that can hold cells of an open sector -- of up to four rings at a time -- once few are
+      const int R_lo = R + 1;
+      int R_hi;
+      const unsigned am = (unsigned)(__ballot(lane < 8 && (my_arcsec & ~done_mask & 0xFFu) != 0u) & 0xFFull);
+      const int n_arc = __popc(am);
+      if (R == 0) {
+        R_hi = min(3, r_max);
+        const int side_w = 2 * R_hi + 1, cells_in_pass = side_w * side_w;
+        for (int t0 = 0; t0 < cells_in_pass; t0 += 64) {
+          const int t = t0 + lane;
+          const int di = t / side_w - R_hi, dj = t % side_w - R_hi;
+          probe(di, dj, t < cells_in_pass && !(di == 0 && dj == 0));
+        }
+      } else if (n_arc >= 5) {
+        R_hi = R_lo;
+        const int cells_in_pass = 8 * R_hi;
+        const float inv_side = 1.0f / (float)(2 * R_hi);
+        for (int t0 = 0; t0 < cells_in_pass; t0 += 64) {
+          const int t = t0 + lane;
           // t / (2 R_hi) without an integer division: (t + 1/2) / (2 R_hi) is at least 1 / (4 R_hi) away from an integer, fp32 is exact enough
           const int side = (int)(((float)t + 0.5f) * inv_side), o = t - side * 2 * R_hi;
-          const int e = o - R_hi;                                // position along the side, as selects: no divergent branches in the pass
-          di = (side == 0) ? -R_hi : (side == 2) ? R_hi : (side == 1) ? e : -e;
-          dj = (side == 1) ? R_hi : (side == 3) ? -R_hi : (side == 0) ? e : -e;
+          int di, dj;
+          ring_cell(R_hi, 2 * side + (o >= R_hi ? 1 : 0), o >= R_hi ? o - R_hi : o, di, dj);
+          probe(di, dj, t < cells_in_pass);
         }
-        const int i = i0 + di, j = j0 + dj;
-        ok = ok && i >= ilo && i <= ihi && j >= jlo && j <= jhi;
-        // everything is computed for every lane at clamped (always valid) indices; ONE predicate guards the insertion
-        const int ic = min(max(i, ilo), ihi), jc = min(max(j, jlo), jhi);
-        const bool inwin = ic >= r0 && ic < r1 && jc >= c0 && jc < c1;
-        const int rk = rank[inwin ? (ic - r0) * ww + (jc - c0) : 0];
-        const double gv = g[ic * W + jc];
-        const double ddx = x0 - a.xs[jc], ddy = y0 - a.ys[ic];
-        const double d = sqrt(ddx * ddx + ddy * ddy);
-        const int s = octant(ddy, ddx);
-        // rk: -1 = conditioning data, < slot = simulated before this cell
-        const bool ins = ok && (inwin ? rk < slot : !isnan(gv)) && d < radius && !((done_mask >> s) & 1u);
-        if (ins) {
-          const int pos = atomicAdd(&L.len[s], 1);
-          long_list |= pos + 1 > kSgsListCap - 64;
-          L.list_d[s][pos] = d; L.list_g[s][pos] = i * W + j;
-          const double qf = d * inv_cert;
-          if (qf < (double)kSgsCertMax) { const int qi = (int)qf; atomicAdd(&L.cert[s][qi >> 1], 1u << (16 * (qi & 1))); }
-        }
+      } else {
+        // rows of a pass: per ring one row of the ring's 8 vertices (4 corners, 4 axis cells: they may fall into the sector on either
+        // side) and one row per open arc (the R' - 1 cells strictly between two vertices); row = arc slot * n_rings + ring, LW lanes per row
+        if (lane < 8 && ((am >> lane) & 1u)) L.arcs[__popc(am & ((1u << lane) - 1u))] = lane;
+        auto lanes_for = [&](int nr) { const int m = max(R_lo + nr - 2, 8); return m > 32 ? 64 : m > 16 ? 32 : m > 8 ? 16 : 8; };
+        int lg_nr = 0;
+        if (R_lo + 1 <= r_max && 2 * (n_arc + 1) * lanes_for(2) <= 64) lg_nr = 1;
+        if (R_lo + 3 <= r_max && 4 * (n_arc + 1) * lanes_for(4) <= 64) lg_nr = 2;
+        const int n_rings = 1 << lg_nr, LW = lanes_for(n_rings), lgw = 31 - __clz(LW);
+        R_hi = R_lo + n_rings - 1;
+        const int total_rows = (n_arc + 1) << lg_nr, rows_per_sub = 64 >> lgw;
         __syncthreads();
-        // a list that could not take another full pass is cut back to the k8 nearest (nothing beyond them can be selected); the lane
-        // whose insertion took a list over that mark knows: the eight lengths are only looked at then
-        if (__ballot(long_list)) {
-          for (int s = 0; s < 8; ++s)
-            if (L.len[s] > kSgsListCap - 64) sgs_prune_sector(L, s, k8, lane);
-          long_list = false;
-        }
+        for (int row0 = 0; row0 < total_rows; row0 += rows_per_sub)
+          for (int col0 = 0; col0 < max(R_hi - 1, 8); col0 += LW) {
+            const int row = row0 + (lane >> lgw), col = col0 + (lane & (LW - 1));
+            const int aslot = row >> lg_nr, Rr = R_lo + (row & (n_rings - 1));
+            const bool vertex = aslot == n_arc;
+            const int gq = vertex ? col : L.arcs[min(aslot, 7)];
+            int di, dj;
+            ring_cell(Rr, gq & 7, vertex ? 0 : col + 1, di, dj);
+            probe(di, dj, row < total_rows && (vertex ? col < 8 : col + 1 < Rr));
+          }
       }
       R = R_hi;
       bool fin = false;
