@@ -414,6 +414,12 @@ int gsm_sgs_set_kriging(gsm_handle h, int32_t ktype, const double* global_mean);
  * SAME batch (every byte of the struct -- zero it before filling -- and n_iters) is submitted and replayed afterwards: one
  * launch per batch instead of up to 7 per iteration; the device buffers must then be static and refilled in place
  * (gsm_sgs_draw_philox / gsm_sgs_draw_pcg64 do).  Asynchronous; gsm_sgs_check reports a raised device flag.
+ * grid_finite != 0: the caller's promise that no cell of `cur` is NaN (it stays so: simulation fills every cell of a block).
+ * A cell's neighbour set and kriging weights depend on WHERE values are, not on the values; with the promise the search reads no
+ * grid value, the records name their cells, and the records of iteration j + 1 are made on a second stream of the handle while
+ * iteration j runs its value pass, transforms, loss and decision (the longest kernel of an iteration leaves the critical path;
+ * the value pass then reads the neighbours' values from the grid).  Same numbers as without the promise.  With NaN cells in
+ * `cur` the promise is false and the neighbour sets would be wrong: leave it 0.
  * gsm_sgs_graph_replays: how many batches of this handle were graph launches (diagnostics / tests). */
 typedef struct gsm_sgs_batch {
   double* cur; double* next; double* proposed;            /* proposed: only with a transformer */
@@ -428,6 +434,7 @@ typedef struct gsm_sgs_batch {
   double radius, sill;
   int64_t cell_off_stride;
   int32_t qt_n, windowed, lag_mi, lag_mj, hw, num_points, max_cells, use_graph;
+  int32_t grid_finite;                                    /* the caller's promise: no NaN in cur (see below) */
 } gsm_sgs_batch;
 int gsm_sgs_iterate(gsm_handle h, const gsm_sgs_batch* batch, int32_t n_iters, void* stream);
 int gsm_sgs_graph_replays(gsm_handle h);

@@ -142,7 +142,7 @@ class SgsBatch(C.Structure):
                                           "x_axis", "y_axis", "lag_cov", "windows", "cell_off", "cell_cnt", "cells", "z", "cell_base", "u",
                                           "resampled", "loss", "bad", "loss_prev", "accept", "loss_rec", "acc_rec")] +
                 [("radius", C.c_double), ("sill", C.c_double), ("cell_off_stride", C.c_int64)] +
-                [(k, C.c_int32) for k in ("qt_n", "windowed", "lag_mi", "lag_mj", "hw", "num_points", "max_cells", "use_graph")])
+                [(k, C.c_int32) for k in ("qt_n", "windowed", "lag_mi", "lag_mj", "hw", "num_points", "max_cells", "use_graph", "grid_finite")])
 
 
 class Vario(C.Structure):

@@ -34,7 +34,8 @@ struct gsm_context {
   double* d_mathtab = nullptr;   // log / sincos table of the coefficient phase (math_tables.h)
   double* d_sgs_part_sum = nullptr; int32_t* d_sgs_part_bad = nullptr; int32_t* d_sgs_ticket = nullptr; size_t sgs_part_cap = 0;   // gsm_sgs_loss partial sums
   // gsm_sgs_blocks scratch: visiting ranks + one record per (chain, cell slot), see SgsArgs
-  void* d_sgs_rec = nullptr; size_t sgs_rec_cells = 0;
+  void* d_sgs_rec[2] = {nullptr, nullptr}; size_t sgs_rec_cells[2] = {0, 0};     // record scratch; [1]: the odd iterations of an overlapped batch
+  hipStream_t sgs_side = nullptr; hipEvent_t sgs_ev[5] = {};                     // gsm_sgs_iterate's second stream (records of iteration j + 1 beside iteration j)
   // gsm_sgs_iterate: the captured launch sequence of one batch (hipGraph), keyed by the bytes of its gsm_sgs_batch + n_iters
   int sgs_ktype = 0; const double* sgs_gmean = nullptr;        // gsm_sgs_set_kriging
   std::vector<char> sgs_graph_key; hipGraphExec_t sgs_graph_exec = nullptr; int sgs_graph_replays = 0;
@@ -144,7 +145,9 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_k2) hipFree(h->d_k2);
   if (h->d_mathtab) hipFree(h->d_mathtab);
   if (h->d_sgs_part_sum) { hipFree(h->d_sgs_part_sum); hipFree(h->d_sgs_part_bad); hipFree(h->d_sgs_ticket); }
-  if (h->d_sgs_rec) hipFree(h->d_sgs_rec);
+  for (int q = 0; q < 2; ++q) if (h->d_sgs_rec[q]) hipFree(h->d_sgs_rec[q]);
+  for (hipEvent_t e : h->sgs_ev) if (e) hipEventDestroy(e);
+  if (h->sgs_side) hipStreamDestroy(h->sgs_side);
   if (h->sgs_graph_exec) hipGraphExecDestroy(h->sgs_graph_exec);
   if (h->d_pcg_tab) hipFree(h->d_pcg_tab);
   if (h->d_k2_off) hipFree(h->d_k2_off);
@@ -926,7 +929,7 @@ extern "C" int gsm_draw_pcg64(gsm_handle h, int32_t n_steps, const gsm_rf_params
 static int sgs_fill(gsm_handle h, SgsArgs& a, double* grids, const double* zcond, const int32_t* windows, const double* x_axis,
                     const double* y_axis, const double* lag_cov, int32_t lag_mi, int32_t lag_mj, int32_t hw, double radius,
                     int32_t num_points, double sill, const int32_t* cell_off, const int32_t* cells, const double* z,
-                    int32_t max_cells, const char* who) {
+                    int32_t max_cells, const char* who, int parity = 0) {
   if (!grids || !windows || !x_axis || !y_axis || !lag_cov || !cell_off || !cells || !z) return fail(h, GSM_E_ARG, std::string(who) + ": NULL pointer");
   if (hw < 1) return fail(h, GSM_E_ARG, std::string(who) + ": search half-width (ceil(radius / grid spacing)) must be >= 1 cell");
   if (num_points < 8 || num_points > 48) return fail(h, GSM_E_UNSUPPORTED, std::string(who) + ": num_points must be in [8, 48]");
@@ -938,18 +941,18 @@ static int sgs_fill(gsm_handle h, SgsArgs& a, double* grids, const double* zcond
   // scratch: per (chain, slot) 48 x (value, weight) and a header; then ranks [n][1024] i32, rank_ok [n] i32
   max_cells = (max_cells + 63) & ~63;                        // record stride: whole 64-cell chunks (sgs_sequence_kernel: one cell per lane)
   const size_t n = (size_t)h->n_chains, cells_cap = n * (size_t)max_cells;
-  if (h->sgs_rec_cells < cells_cap) {
+  if (h->sgs_rec_cells[parity] < cells_cap) {
     // a captured batch (gsm_sgs_iterate's hipGraph) holds the old scratch pointers: it must not be replayed
     if (h->sgs_graph_exec) { hipGraphExecDestroy(h->sgs_graph_exec); h->sgs_graph_exec = nullptr; }
     h->sgs_graph_key.clear();
-    if (h->d_sgs_rec) { hipFree(h->d_sgs_rec); h->d_sgs_rec = nullptr; h->sgs_rec_cells = 0; }
+    if (h->d_sgs_rec[parity]) { hipFree(h->d_sgs_rec[parity]); h->d_sgs_rec[parity] = nullptr; h->sgs_rec_cells[parity] = 0; }
     const size_t bytes = n * 1024 * 4 + n * 4 + 64 + cells_cap * (sizeof(SgsCellHdr) + 48 * sizeof(double2));
-    hipError_t e = hipMalloc(&h->d_sgs_rec, bytes);
+    hipError_t e = hipMalloc(&h->d_sgs_rec[parity], bytes);
     if (e != hipSuccess) return fail(h, GSM_E_HIP, std::string(who) + ": " + hipGetErrorString(e));
-    h->sgs_rec_cells = cells_cap;
+    h->sgs_rec_cells[parity] = cells_cap;
   }
-  char* p = (char*)h->d_sgs_rec;
-  const size_t cap = h->sgs_rec_cells;
+  char* p = (char*)h->d_sgs_rec[parity];
+  const size_t cap = h->sgs_rec_cells[parity];
   a.rec_vw = (double2*)p; p += cap * 48 * sizeof(double2);
   a.rec_hdr = (SgsCellHdr*)p; p += cap * sizeof(SgsCellHdr);
   a.rank = (int32_t*)p; p += n * 1024 * 4;
@@ -958,7 +961,7 @@ static int sgs_fill(gsm_handle h, SgsArgs& a, double* grids, const double* zcond
   a.grid = grids; a.zcond = zcond; a.win = windows; a.xs = x_axis; a.ys = y_axis; a.lag = lag_cov;
   a.hw = hw; a.mi = lag_mi; a.mj = lag_mj; a.num_points = num_points; a.radius = radius; a.sill = sill;
   a.cell_off = cell_off; a.cells = cells; a.z = z; a.err = h->d_err; a.max_cells = max_cells;
-  a.ktype = h->sgs_ktype; a.gmean = h->sgs_gmean;
+  a.ktype = h->sgs_ktype; a.gmean = h->sgs_gmean; a.defer = 0;
   return GSM_OK;
 }
 
@@ -1173,15 +1176,58 @@ static int sgs_issue(gsm_handle h, const gsm_sgs_batch* b, int32_t n_iters, void
   const int64_t n = h->n_chains;
   const bool qt = b->qt_n > 0;
   const int64_t map = n * (int64_t)h->H * h->W;
+  hipStream_t main_st = (hipStream_t)st;
+  // The kriging weights of an iteration do not depend on the values of the grid, only on where values are: when the caller
+  // promises that every cell holds one (grid_finite), the records of iteration j + 1 (sgs_rank_kernel, sgs_weights_kernel) are made on a
+  // second stream while iteration j runs its value pass, transforms, loss and decision -- the longest kernel of an iteration leaves the
+  // critical path.  Two sets of record scratch, by the parity of the iteration.
+  const bool overlap = b->grid_finite != 0 && n_iters > 1;
+  if (overlap && !h->sgs_side) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->sgs_side, hipStreamNonBlocking));
+    for (hipEvent_t& e : h->sgs_ev) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  auto fill = [&](int32_t j, SgsArgs& a) -> int {
+    const int64_t base = b->cell_base ? b->cell_base[j] : 0;
+    int rc = sgs_fill(h, a, b->next, b->zcond, b->windows + 4 * n * j, b->x_axis, b->y_axis, b->lag_cov, b->lag_mi, b->lag_mj, b->hw, b->radius,
+                      b->num_points, b->sill, b->cell_off + b->cell_off_stride * j, b->cells + 2 * base, b->z + base, b->max_cells,
+                      "gsm_sgs_iterate", overlap ? (j & 1) : 0);
+    if (rc) return rc;
+    a.cell_cnt = b->cell_cnt ? b->cell_cnt + n * j : nullptr; a.trace = nullptr; a.nbr_trace = nullptr;
+    a.defer = overlap ? 1 : 0;
+    return GSM_OK;
+  };
+  hipEvent_t* ev_w = h->sgs_ev;            // [2] records of parity p are complete
+  hipEvent_t* ev_s = h->sgs_ev + 2;        // [2] the value pass that read the records of parity p is over
+  SgsArgs a_cur{}, a_nxt{};
+  int rc;
+  if (overlap) {
+    SgsArgs t0{}, t1{};
+    if ((rc = fill(0, t0)) || (rc = fill(1, t1))) return rc;       // both sets of scratch exist before anything is enqueued
+    HIPCHK(h, hipEventRecord(h->sgs_ev[4], main_st));               // fork: whatever made the draws is on the main stream
+    HIPCHK(h, hipStreamWaitEvent(h->sgs_side, h->sgs_ev[4], 0));
+    a_cur = t0;
+    HIPCHK(h, launch_sgs_weights(a_cur, a_cur.max_cells, h->sgs_side));
+    HIPCHK(h, hipEventRecord(ev_w[0], h->sgs_side));
+  }
   for (int32_t j = 0; j < n_iters; ++j) {
     const int32_t* win = b->windows + 4 * n * j;
     const double* u = b->u + n * j;
-    const int64_t base = b->cell_base ? b->cell_base[j] : 0;
-    int rc;
+    if (overlap && j + 1 < n_iters) {
+      if (j >= 1) HIPCHK(h, hipStreamWaitEvent(h->sgs_side, ev_s[(j + 1) & 1], 0));     // iteration j - 1 has read that set of records
+      if ((rc = fill(j + 1, a_nxt))) return rc;
+      HIPCHK(h, launch_sgs_weights(a_nxt, a_nxt.max_cells, h->sgs_side));
+      HIPCHK(h, hipEventRecord(ev_w[(j + 1) & 1], h->sgs_side));
+    }
     if (qt && (rc = gsm_qt_transform(h, b->qt_quantiles, b->qt_references, b->qt_n, b->cur, b->next, map, 0, st))) return rc;   // MCMC.py:1766
-    if ((rc = gsm_sgs_blocks_batch(h, b->next, b->zcond, win, b->x_axis, b->y_axis, b->lag_cov, b->lag_mi, b->lag_mj, b->hw, b->radius,
-                                   b->num_points, b->sill, b->cell_off + b->cell_off_stride * j, b->cell_cnt ? b->cell_cnt + n * j : nullptr,
-                                   b->cells + 2 * base, b->z + base, b->max_cells, st))) return rc;
+    if (overlap) {
+      HIPCHK(h, hipStreamWaitEvent(main_st, ev_w[j & 1], 0));
+      HIPCHK(h, launch_sgs_sequence(a_cur, main_st));
+      HIPCHK(h, hipEventRecord(ev_s[j & 1], main_st));
+      a_cur = a_nxt;
+    } else {
+      if ((rc = fill(j, a_cur))) return rc;
+      HIPCHK(h, launch_sgs_blocks(a_cur, a_cur.max_cells, main_st));
+    }
     if (b->windowed) {
       if ((rc = gsm_sgs_finish(h, b->cur, b->next, b->trend, b->energy, b->state, win, u, b->resampled, b->accept,
                                b->loss_rec ? b->loss_rec + j : nullptr, b->acc_rec ? b->acc_rec + j : nullptr, n_iters, st))) return rc;
@@ -1194,7 +1240,7 @@ static int sgs_issue(gsm_handle h, const gsm_sgs_batch* b, int32_t n_iters, void
     if ((rc = sgs_parts_ensure(h))) return rc;
     HIPCHK(h, launch_sgs_loss_tail(h->S, h->n_chains, b->trend, h->d_sgs_part_sum, h->d_sgs_part_bad, h->d_sgs_ticket, b->loss, b->bad, u,
                                    b->loss_prev, b->accept, b->loss_rec ? b->loss_rec + j : nullptr, b->acc_rec ? b->acc_rec + j : nullptr,
-                                   n_iters, qt ? 1 : 2, b->cur, qt ? b->proposed : b->next, b->resampled, win, (hipStream_t)st));
+                                   n_iters, qt ? 1 : 2, b->cur, qt ? b->proposed : b->next, b->resampled, win, main_st));
   }
   return GSM_OK;
 }

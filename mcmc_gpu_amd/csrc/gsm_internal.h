@@ -198,6 +198,8 @@ struct SgsArgs {
   const double* lag;       // [(2 mi + 1) * (2 mj + 1)] covariance at integer lag (di, dj), |di| <= mi, |dj| <= mj
   int hw, mi, mj, num_points;
   int ktype;               // 0 ordinary kriging (ok_solve), 1 simple kriging (sk_solve) with gmean
+  int defer;               // 1: every cell outside the blocks holds a value (the caller's promise); sgs_weights_kernel then reads no grid value
+                           //    -- the records name the cells -- and can run while the grid of the iteration before is still being written
   const double* gmean;     // [n_chains] global mean of each chain's conditioning values (simple kriging only)
   double radius, sill;
   const int32_t* cell_off; // [n_chains+1] (or [n_chains] with cell_cnt)
@@ -217,6 +219,8 @@ struct SgsArgs {
                            //  the block; its kriging weight)
 };
 hipError_t launch_sgs_blocks(const SgsArgs& a, int launch_cells, hipStream_t st);
+hipError_t launch_sgs_weights(const SgsArgs& a, int launch_cells, hipStream_t st);     // ranks + records
+hipError_t launch_sgs_sequence(const SgsArgs& a, hipStream_t st);                      // value pass
 struct SgsDrawArgs {
   int H, W, n_chains, n_iters;
   int64_t iter0;

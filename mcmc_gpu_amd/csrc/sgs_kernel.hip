@@ -61,7 +61,11 @@ constexpr int kSgsMaxWin = 1024;
 constexpr int kSgsListCap = GSM_SGS_LISTCAP;
 constexpr int kSgsCertMax = 64;           // rings with certification counters (the driver's 30 km at 500 m = 60 rings); beyond, a sector
                                           // completes by exhaustion only
-constexpr uint64_t kSgsPendingTag = 0x7FF8C0DE00000000ull;   // neighbour record: NaN-boxed block-local index of a cell visited earlier
+constexpr uint64_t kSgsPendingTag = 0x7FF8C0DE00000000ull;   // neighbour record: NaN-boxed (visiting slot << 16 | block-local index) of a cell visited earlier
+// with SgsArgs::defer the values of the other neighbours are not in the record either (the weights do not depend on them: the
+// records of an iteration can then be made while the iteration before is still running):
+constexpr uint64_t kSgsWindowTag = 0x7FF8C0DF00000000ull;    // | block-local index: conditioning data inside the block (sgs_sequence_kernel's overlay holds it)
+constexpr uint64_t kSgsGridTag = 0x7FF8C0E000000000ull;      // | flat grid index: a cell outside the block, read from the grid by sgs_sequence_kernel
 
 __device__ __forceinline__ double wave_sum_f64(double v) { return dev::wave64_sum(v); }     // DPP tree, wave-uniform result
 // two sums over the 64 lanes at once, results wave-uniform.  The halves are folded first -- v_permlane32_swap (gfx950) exchanges the
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
       const int ic = min(max(i, ilo), ihi), jc = min(max(j, jlo), jhi);
       const bool inwin = ic >= r0 && ic < r1 && jc >= c0 && jc < c1;
       const int rk = rank[inwin ? (ic - r0) * ww + (jc - c0) : 0];
-      const double gv = g[ic * W + jc];
+      const double gv = a.defer ? 0.0 : g[ic * W + jc];          // defer: every cell outside the block holds a value (the caller's promise)
       const double ddx = x0 - a.xs[jc], ddy = y0 - a.ys[ic];
       const double d = sqrt(ddx * ddx + ddy * ddy);
       const int s = octant(ddy, ddx);
@@ -472,6 +476,8 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
       const int nb_slot = inblk ? rank[nb_pos] : -1;
       if (nb_slot >= 0)          // simulated earlier in this block: its visiting slot and its block-local index (both < 1024)
         vw.x = __builtin_bit_cast(double, kSgsPendingTag | ((uint64_t)nb_slot << 16) | (uint64_t)nb_pos);
+      else if (a.defer)
+        vw.x = __builtin_bit_cast(double, inblk ? (kSgsWindowTag | (uint64_t)nb_pos) : (kSgsGridTag | (uint64_t)(uint32_t)gg));
       else
         vw.x = (inblk && a.zcond) ? a.zcond[gg] : g[gg];
     }
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(64 * kSeqWaves) void sgs_sequence_kernel(const SgsA
   const int r0 = a.win[4 * chain], r1 = a.win[4 * chain + 1], c0 = a.win[4 * chain + 2], c1 = a.win[4 * chain + 3];
   const int wh = r1 - r0, ww = c1 - c0;
   const int k_lo = a.cell_off[chain], cnt = a.cell_cnt ? a.cell_cnt[chain] : a.cell_off[chain + 1] - k_lo;
-  const int np4 = (a.num_points + 3) & ~3, np8 = (a.num_points + 7) & ~7;
+  const int np8 = (a.num_points + 7) & ~7;
   const size_t rec0 = (size_t)chain * a.max_cells;              // a multiple of 64 (sgs_fill)
   const double* __restrict__ vw_src = (const double*)(a.rec_vw + rec0 * kSgsMaxPts);
   const double4* __restrict__ hdr_src = (const double4*)(a.rec_hdr + rec0);
@@ -550,29 +556,40 @@ __global__ __launch_bounds__(64 * kSeqWaves) void sgs_sequence_kernel(const SgsA
     const uint64_t nop = __builtin_bit_cast(uint64_t, hd.x);
     const int n = (j < cnt) ? (int)(uint32_t)nop : -2, op = (int)(nop >> 32);
     const double sdz = hd.y, var = hd.z, c1 = hd.w;
-    // ---- gather ----  (no branches; by groups of four entries: the group's LDS reads first, then its sums and tile entries)
+    // ---- gather ----  (no branches; this wave's entries 4 wave + 16 k + u: all their reads first -- records from LDS, deferred values
+    // from the grid, earlier cells from the overlay --, then the sums and the tile's entries)
     double sv = 0.0, swv = 0.0;
     uint64_t mask = 0;
-    for (int e0 = 4 * wave; e0 < np4; e0 += 4 * kSeqWaves) {
-      double2 r[4];
-      double ov[4];
+    {
+      double2 r[12];
+      double gvv[12], ov[12];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) r[u] = stage[(e0 + u) * 64 + lane];
+      for (int q = 0; q < 12; ++q) r[q] = stage[(4 * wave + 16 * (q >> 2) + (q & 3)) * 64 + lane];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint64_t bits = __builtin_bit_cast(uint64_t, r[u].x);
-        const bool early = (e0 + u < n) && ((bits & 0xFFFFFFFF00000000ull) == kSgsPendingTag) && ((int)((uint32_t)bits >> 16) < kc);
-        ov[u] = overlay[early ? ((uint32_t)bits & 0xFFFFu) : 0u];
+      for (int q = 0; q < 12; ++q) {
+        const int e = 4 * wave + 16 * (q >> 2) + (q & 3);
+        const uint64_t bits = __builtin_bit_cast(uint64_t, r[q].x);
+        const uint32_t hi = (uint32_t)(bits >> 32), lo = (uint32_t)bits;
+        gvv[q] = g[(e < n && hi == (uint32_t)(kSgsGridTag >> 32)) ? lo : 0u];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u;
-        const uint64_t bits = __builtin_bit_cast(uint64_t, r[u].x);
-        const double w = r[u].y;
-        const bool pend = (bits & 0xFFFFFFFF00000000ull) == kSgsPendingTag;
-        const int ks = (int)((uint32_t)bits >> 16) - kc;         // >= 0: a cell of this chunk (visited before this one: ks < lane)
+      for (int q = 0; q < 12; ++q) {
+        const int e = 4 * wave + 16 * (q >> 2) + (q & 3);
+        const uint64_t bits = __builtin_bit_cast(uint64_t, r[q].x);
+        const uint32_t hi = (uint32_t)(bits >> 32), lo = (uint32_t)bits;
+        const bool early = (e < n) && ((hi == (uint32_t)(kSgsPendingTag >> 32) && (int)(lo >> 16) < kc) || hi == (uint32_t)(kSgsWindowTag >> 32));
+        ov[q] = overlay[early ? (lo & 0xFFFFu) : 0u];
+      }
+#pragma unroll
+      for (int q = 0; q < 12; ++q) {
+        const int e = 4 * wave + 16 * (q >> 2) + (q & 3);
+        const uint64_t bits = __builtin_bit_cast(uint64_t, r[q].x);
+        const uint32_t hi = (uint32_t)(bits >> 32), lo = (uint32_t)bits;
+        const double w = r[q].y;
+        const bool pend = hi == (uint32_t)(kSgsPendingTag >> 32), inwin = hi == (uint32_t)(kSgsWindowTag >> 32), ingrid = hi == (uint32_t)(kSgsGridTag >> 32);
+        const int ks = (int)(lo >> 16) - kc;                     // >= 0: a cell of this chunk (visited before this one: ks < lane)
         const bool here = (e < n) && pend && ks >= 0, known = (e < n) && !(pend && ks >= 0);
-        const double v = pend ? ov[u] : r[u].x;
+        const double v = ingrid ? gvv[q] : ((pend || inwin) ? ov[q] : r[q].x);
         const double wv = w * v;
         sv += known ? v : 0.0;
         swv += known ? wv : 0.0;
@@ -613,12 +630,24 @@ __global__ __launch_bounds__(64 * kSeqWaves) void sgs_sequence_kernel(const SgsA
   for (int p = threadIdx.x; p < wh * ww; p += 64 * kSeqWaves) g[(size_t)(r0 + p / ww) * W + c0 + p % ww] = overlay[p];
 }
 
-hipError_t launch_sgs_blocks(const SgsArgs& a, int launch_cells, hipStream_t st) {
-  if (a.hw < 1 || a.num_points < 8 || a.num_points > kSgsMaxPts || a.H < 2 || a.W < 2 || a.H > 32767 || a.W > 32767) return hipErrorInvalidValue;
+static bool sgs_args_ok(const SgsArgs& a) {
+  return !(a.hw < 1 || a.num_points < 8 || a.num_points > kSgsMaxPts || a.H < 2 || a.W < 2 || a.H > 32767 || a.W > 32767);
+}
+// the two halves of launch_sgs_blocks: the records of every cell (visiting ranks, then search + kriging weights), and the value pass
+hipError_t launch_sgs_weights(const SgsArgs& a, int launch_cells, hipStream_t st) {
+  if (!sgs_args_ok(a)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(sgs_rank_kernel, dim3(a.n_chains), dim3(256), 0, st, a);
   if (launch_cells > 0) hipLaunchKernelGGL(sgs_weights_kernel, dim3(launch_cells, a.n_chains), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_sgs_sequence(const SgsArgs& a, hipStream_t st) {
+  if (!sgs_args_ok(a)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(sgs_sequence_kernel, dim3(a.n_chains), dim3(64 * kSeqWaves), 0, st, a);
   return hipGetLastError();
+}
+hipError_t launch_sgs_blocks(const SgsArgs& a, int launch_cells, hipStream_t st) {
+  hipError_t e = launch_sgs_weights(a, launch_cells, st);
+  return e != hipSuccess ? e : launch_sgs_sequence(a, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

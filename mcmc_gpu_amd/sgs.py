@@ -472,8 +472,12 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
             b.loss_rec, b.acc_rec = pv(d_lrec), pv(d_arec)
             b.radius, b.sill = rad, float(vario["sill"])
             b.lag_mi, b.lag_mj, b.hw, b.num_points, b.max_cells, b.use_graph = lag_mi, lag_mj, hw, npts, max_cells, int(use_graph)
+            b.grid_finite = int(grid_finite)
             return b
 
+        # no NaN in the beds (and none can appear: every cell of a block is simulated): gsm_sgs_iterate may then make the records of
+        # iteration j + 1 while iteration j is still running (include/gsm.h: grid_finite).  GSM_SGS_OVERLAP=0 turns that off.
+        grid_finite = os.environ.get('GSM_SGS_OVERLAP', '1') != '0' and bool(torch.isfinite(cur).all())
         it_done = 0
         if philox and n_iter > 0:
             # device draws refill the SAME buffers batch after batch: the launch sequence of a full batch CAN be a hipGraph
