@@ -487,34 +487,57 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
             use_graph = batch > 1 and os.environ.get('GSM_SGS_GRAPH', '0') != '0'
             i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
             kmax = min(batch, n_iter)
-            b_win, b_blk, b_off, b_cnt = i32(kmax * n * 4), i32(kmax * n * 4), i32(kmax * n), i32(kmax * n)
-            d_cells = i32(kmax * n * max_cells, 2); d_z = torch.empty(kmax * n * max_cells, dtype=torch.float64, device=dev)
-            b_us = torch.empty(kmax * n, dtype=torch.float64, device=dev)
+            # two sets of draw buffers: the draws of batch b + 1 (they depend on the generators only, never on the chains' state) are
+            # made on their own stream while batch b iterates.  A captured batch needs ONE set of static buffers: no second set then.
+            n_sets = 1 if (use_graph or os.environ.get('GSM_SGS_DRAW_AHEAD', '1') == '0') else 2
+            sets = []
+            for _ in range(n_sets):
+                sets.append(dict(win=i32(kmax * n * 4), blk=i32(kmax * n * 4), off=i32(kmax * n), cnt=i32(kmax * n),
+                                 cells=i32(kmax * n * max_cells, 2), z=torch.empty(kmax * n * max_cells, dtype=torch.float64, device=dev),
+                                 us=torch.empty(kmax * n, dtype=torch.float64, device=dev)))
             b_lrec = torch.empty(n * kmax, dtype=torch.float64, device=dev); b_arec = torch.empty(n * kmax, dtype=torch.uint8, device=dev)
             d_lprev = f64(loss_prev); d_acc = torch.empty(n, dtype=torch.uint8, device=dev)
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
+            draw_st = torch.cuda.Stream(dev) if n_sets == 2 else side
+            draw_st.wait_stream(torch.cuda.current_stream(dev))
+
+            def views(bs, kb):
+                return (bs['win'][:kb * n * 4].view(kb, n, 4), bs['blk'][:kb * n * 4].view(kb, n, 4), bs['off'][:kb * n].view(kb, n),
+                        bs['cnt'][:kb * n].view(kb, n), bs['us'][:kb * n].view(kb, n))
+
+            def draw(bs, it0, kb):
+                """the draws of iterations it0 .. it0 + kb - 1 into the buffer set bs, on the draw stream"""
+                d_win, d_blk, d_off, d_cnt, d_us = views(bs, kb)
+                with torch.cuda.device(dev), torch.cuda.stream(draw_st):
+                    args = (kb, _ptr(d_region), _ptr(d_isdata), int(chain.block_min_x), int(chain.block_max_x), int(chain.block_min_y),
+                            int(chain.block_max_y), max_cells, _ptr(d_win), _ptr(d_blk), _ptr(d_off), _ptr(d_cnt), _ptr(bs['cells']), _ptr(bs['z']),
+                            _ptr(d_us), draw_st.cuda_stream)
+                    if pcg64:
+                        eng._check(lib.gsm_sgs_draw_pcg64(h, _ptr(d_gen), *args))
+                    else:
+                        eng._check(lib.gsm_sgs_draw_philox(h, _ptr(d_seeds), int(philox_iter0) + it0, *args))
+            if host_nst is None:
+                draw(sets[0], 0, min(batch, n_iter))
         # (a transformer of another kind than scikit-learn's is called on the host once per iteration: the loop further down)
+        n_batch = 0
         while philox and host_nst is None and it_done < n_iter:
             kb = min(batch, n_iter - it_done)
-            d_win, d_blk, d_off, d_cnt = b_win[:kb * n * 4].view(kb, n, 4), b_blk[:kb * n * 4].view(kb, n, 4), b_off[:kb * n].view(kb, n), b_cnt[:kb * n].view(kb, n)
-            d_us = b_us[:kb * n].view(kb, n)
+            bs = sets[n_batch % n_sets]
+            d_win, d_blk, d_off, d_cnt, d_us = views(bs, kb)
             d_lrec, d_arec = b_lrec[:n * kb].view(n, kb), b_arec[:n * kb].view(n, kb)
+            side.wait_stream(draw_st)                                  # this batch's draws
+            nxt_kb = min(batch, n_iter - it_done - kb)
+            if nxt_kb > 0 and n_sets == 2:
+                draw(sets[(n_batch + 1) % 2], it_done + kb, nxt_kb)   # the other set: the batch that used it is over (its records were downloaded)
             with torch.cuda.device(dev), torch.cuda.stream(side):
-                if pcg64:
-                    eng._check(lib.gsm_sgs_draw_pcg64(h, _ptr(d_gen), kb, _ptr(d_region), _ptr(d_isdata),
-                                                      int(chain.block_min_x), int(chain.block_max_x), int(chain.block_min_y), int(chain.block_max_y),
-                                                      max_cells, _ptr(d_win), _ptr(d_blk), _ptr(d_off), _ptr(d_cnt), _ptr(d_cells), _ptr(d_z),
-                                                      _ptr(d_us), eng._stream()))
-                else:
-                    eng._check(lib.gsm_sgs_draw_philox(h, _ptr(d_seeds), int(philox_iter0) + it_done, kb, _ptr(d_region), _ptr(d_isdata),
-                                                       int(chain.block_min_x), int(chain.block_max_x), int(chain.block_min_y), int(chain.block_max_y),
-                                                       max_cells, _ptr(d_win), _ptr(d_blk), _ptr(d_off), _ptr(d_cnt), _ptr(d_cells), _ptr(d_z),
-                                                       _ptr(d_us), eng._stream()))
-                bt = make_batch(d_win, d_off, n, d_cnt, d_cells, d_z, d_us, d_lrec, d_arec, use_graph=use_graph)
-                eng._check(lib.gsm_sgs_iterate(h, C.byref(bt), kb, eng._stream()))
-                eng._check(lib.gsm_sgs_check(h, eng._stream()))
+                bt = make_batch(d_win, d_off, n, d_cnt, bs['cells'], bs['z'], d_us, d_lrec, d_arec, use_graph=use_graph)
+                eng._check(lib.gsm_sgs_iterate(h, C.byref(bt), kb, side.cuda_stream))
+                eng._check(lib.gsm_sgs_check(h, side.cuda_stream))
                 lrec_h, arec_h, blk_h = d_lrec.cpu().numpy(), d_arec.cpu().numpy(), d_blk.cpu().numpy()
+            if nxt_kb > 0 and n_sets == 1:
+                draw(sets[0], it_done + kb, nxt_kb)
+            n_batch += 1
             loss_cache[:, it_done:it_done + kb] = lrec_h
             step_cache[:, it_done:it_done + kb] = arec_h
             blocks_cache[:, it_done:it_done + kb] = blk_h.transpose(1, 0, 2)
@@ -528,6 +551,7 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
             it_done += kb
             if it_done >= n_iter:
                 torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.current_stream(dev).wait_stream(draw_st)
                 global LAST_GRAPH_REPLAYS
                 LAST_GRAPH_REPLAYS = int(lib.gsm_sgs_graph_replays(h))
             if progress_bar is not None:
@@ -596,8 +620,9 @@ def run_many_sgs(chain, initial_beds, rngs, n_iter, only_save_last_bed=True, inf
         for it in range(it_done, n_iter):
             if philox:
                 # device draws of ONE iteration (a host-side transformer sits between the draws and the simulation)
-                d_win, d_blk1 = b_win[:n * 4].view(n, 4), b_blk[:n * 4].view(n, 4)
-                d_off, d_cnt, d_us1 = b_off[:n], b_cnt[:n], b_us[:n]
+                bs = sets[0]
+                d_win, d_blk1 = bs['win'][:n * 4].view(n, 4), bs['blk'][:n * 4].view(n, 4)
+                d_off, d_cnt, d_us1, d_cells, d_z = bs['off'][:n], bs['cnt'][:n], bs['us'][:n], bs['cells'], bs['z']
                 with torch.cuda.device(dev):
                     if pcg64:
                         eng._check(lib.gsm_sgs_draw_pcg64(h, _ptr(d_gen), 1, _ptr(d_region), _ptr(d_isdata),
