@@ -447,6 +447,30 @@ def test_graph_replay_of_a_batch_equals_the_eager_launches(monkeypatch, transfor
             assert np.array_equal(np.asarray(x[k], dtype=float), np.asarray(y[k], dtype=float), equal_nan=True), k
 
 
+@pytest.mark.parametrize("transform,pcg64,light", [(True, False, False), (False, False, True), (True, True, False)])
+def test_records_made_ahead_and_draws_made_ahead_change_nothing(monkeypatch, transform, pcg64, light):
+    """With no NaN in the beds gsm_sgs_iterate makes the records of iteration j + 1 (ranks, search, kriging weights) on a second
+    stream while iteration j runs -- the records then name their cells and the value pass reads the values from the grid (gsm.h:
+    grid_finite) --, and run_many_sgs draws batch b + 1 while batch b iterates.  Neither changes a number: every record and the
+    generators' final states are identical bit for bit to the launches in the reference's order (MCMC.py:1741-1822)."""
+    from mcmc_gpu_amd import sgs, synthetic
+    res = []
+    for overlap, ahead in (("1", "1"), ("0", "0"), ("1", "0")):
+        monkeypatch.setenv("GSM_SGS_OVERLAP", overlap)
+        monkeypatch.setenv("GSM_SGS_DRAW_AHEAD", ahead)
+        prob, ch = synthetic.sgs_template(48 if not light else 32, transform=transform, light=light)
+        beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(3)]
+        rngs = [np.random.default_rng(170 + i) for i in range(3)]
+        out, rngs = sgs.run_many_sgs(ch, beds, rngs, 100, philox_seeds=None if pcg64 else [21 + i for i in range(3)], pcg64=pcg64)
+        res.append((out, [r.bit_generator.state for r in rngs]))
+    for other, so in res[1:]:
+        assert so == res[0][1]
+        for x, y in zip(res[0][0], other):
+            for k in (0, 3, 4, 5, 6):
+                assert np.array_equal(np.asarray(x[k], dtype=float), np.asarray(y[k], dtype=float), equal_nan=True), k
+    assert sum(float(np.asarray(o[4]).sum()) for o in res[0][0]) > 0      # some proposals were accepted: the commit path ran
+
+
 @pytest.mark.parametrize("tag", ["ok", "sk", "skm"])
 def test_sgs_function_ok_and_sk_equal_reference_fixture(tag):
     """Golden F12: the reference's module-level MCMC.sgs (MCMC.py:91-173) with ordinary and simple kriging (_krige.py:5-44, :46-81;
