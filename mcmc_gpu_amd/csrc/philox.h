@@ -66,4 +66,8 @@ GSM_HD double u01_open0_from(uint32_t lo, uint32_t hi) {
   return (double)((v >> 11) + 1) * (1.0 / 9007199254740992.0);
 }
 
+// one 32-bit word per uniform (the spectrum's normals: four per Philox block): (0, 1] for the logarithm, [0, 1) for the angle
+GSM_HD double u01_open0_from32(uint32_t w) { return ((double)w + 1.0) * (1.0 / 4294967296.0); }
+GSM_HD double u01_from32(uint32_t w) { return (double)w * (1.0 / 4294967296.0); }
+
 }  // namespace gsm

@@ -84,6 +84,25 @@ __device__ __forceinline__ void normals2(uint64_t seed, int64_t step, uint32_t s
   g2 = rad * s;
 }
 
+// Four standard normals from ONE Philox block, a 32-bit word per uniform: (x, y) -> (g1, g2), (z, w) -> (h1, h2).  The spectrum's
+// coefficients are drawn this way (coef_items: a work item needs four normals, for rows ky and bh - ky): the Philox rounds were a
+// quarter of the coefficient phase's instructions and the phase 28 % of the fused kernel's.  2^-32 steps in the uniforms bound
+// |normal| by sqrt(64 ln 2) = 6.66 (probability 2.7e-11 per draw beyond it with exact normals) -- each normal is one of thousands of
+// coefficients of a field that is standardised afterwards.  Restated by oracle/philox_oracle.normals4.
+__device__ __forceinline__ void normals4(uint64_t seed, int64_t step, uint32_t stream, uint32_t idx, double& g1, double& g2,
+                                         double& h1, double& h2, const double* mt) {
+  uint32_t k0 = (uint32_t)(seed & 0xFFFFFFFFu), k1 = (uint32_t)(seed >> 32);
+  asm volatile("" : "+s"(k0), "+s"(k1));                       // see normals2
+  const u32x4 r = philox_draw(((uint64_t)k1 << 32) | k0, step, stream, idx);
+  const double ra = sqrt_lean(-2.0 * log_tab(u01_open0_from32(r.x), mt));
+  const double rb = sqrt_lean(-2.0 * log_tab(u01_open0_from32(r.z), mt));
+  double s, c;
+  sincos_tab(u01_from32(r.y), mt, s, c);
+  g1 = ra * c; g2 = ra * s;
+  sincos_tab(u01_from32(r.w), mt, s, c);
+  h1 = rb * c; h2 = rb * s;
+}
+
 // normals2 for per-LANE seeds (the Cholesky generator's z: every lane of a wave serves another chain)
 __device__ __forceinline__ void normals2_key(uint64_t seed, int64_t step, uint32_t stream, uint32_t idx, double& g1, double& g2,
                                              const double* mt) {
@@ -232,10 +251,9 @@ __device__ __forceinline__ void coef_items(const int t, const int i_lo, const in
     } else {
       if (a.dbg & 1) { amp = 1.0; g1 = ky; g2 = kx; h1 = 1.0; h2 = 2.0; }
       else {
-        normals2(seed, step, kStreamSpectrum, (uint32_t)(ky * ncol + kx), g1, g2, mt);
-        // drawn unconditionally (counter-based: an unused draw costs nothing downstream): one straight-line block for
-        // both Box-Muller evaluations, so the two chains interleave
-        normals2(seed, step, kStreamSpectrum, (uint32_t)(kyc * ncol + kx), h1, h2, mt);
+        // the four normals of the item -- (g1, g2) for row ky, (h1, h2) for row bh - ky -- from one Philox block at counter
+        // ky * ncol + kx; evaluated unconditionally: one straight-line block, so the two Box-Muller chains interleave
+        normals4(seed, step, kStreamSpectrum, (uint32_t)(ky * ncol + kx), g1, g2, h1, h2, mt);
         if (!paired) { h1 = 0.0; h2 = 0.0; }
         amp = spectral_amp(P, sc, k2, mt);
       }

@@ -68,6 +68,17 @@ def normals2(seed, step, stream, idx):
     return rad * np.cos(ang), rad * np.sin(ang)
 
 
+def normals4(seed, step, stream, idx):
+    """Four normals from one Philox block, one 32-bit word per uniform (proposal_device.h: normals4): (x, y) -> (g1, g2),
+    (z, w) -> (h1, h2); u for the logarithm in (0, 1], for the angle in [0, 1)."""
+    r = draw(seed, step, stream, idx).astype(np.float64)
+    two32 = 1.0 / 4294967296.0
+    ra = np.sqrt(-2.0 * np.log((r[..., 0] + 1.0) * two32))
+    rb = np.sqrt(-2.0 * np.log((r[..., 2] + 1.0) * two32))
+    aa, ab = 2.0 * np.pi * (r[..., 1] * two32), 2.0 * np.pi * (r[..., 3] * two32)
+    return ra * np.cos(aa), ra * np.sin(aa), rb * np.cos(ab), rb * np.sin(ab)
+
+
 def wavenumber(n, res):
     k = np.arange(n)
     kk = np.where(k < (n + 1) // 2, k, k - n)
@@ -116,8 +127,15 @@ def proposal(seed, step, rf, pairs, masks, centres, W, resolution):
     ncol = bw // 2 + 1
 
     amp = amplitude_half(bh, bw, resolution, rf.model_name, range_x, range_y, rf.smoothness)
-    idx = np.arange(bh * ncol).reshape(bh, ncol)
-    g1, g2 = normals2(seed, step, STREAM_SPECTRUM, idx)
+    # rows ky <= bh / 2 draw: the block at counter ky * ncol + kx holds the normals of row ky (first pair) and of row bh - ky (second
+    # pair; unused for the two rows that are their own partners)
+    hh = bh // 2
+    idx = np.arange((hh + 1) * ncol).reshape(hh + 1, ncol)
+    a1, a2, b1, b2 = normals4(seed, step, STREAM_SPECTRUM, idx)
+    g1 = np.zeros((bh, ncol)); g2 = np.zeros((bh, ncol))
+    g1[: hh + 1], g2[: hh + 1] = a1, a2
+    for ky in range(1, hh):
+        g1[bh - ky], g2[bh - ky] = b1[ky], b2[ky]
     X = amp * (g1 * math.sqrt(0.5)) + 1j * (amp * (g2 * math.sqrt(0.5)))
     kyc = (bh - np.arange(bh)) % bh
     for kx in (0, bw // 2):
