@@ -306,8 +306,8 @@ def measure(args, H, n_local, generator, state, inner, batch, steps, warmup, ran
 
 
 # sgs_weights_kernel: vector wave-instructions per simulated cell at the driver configuration (48 neighbours: ring search + 49-step
-# Gauss-Jordan in registers), rocprofv3 SQ_INSTS_VALU of profiles/r03_sgs_pmc_256chains.txt / simulated cells of that run
-SGS_VALU_PER_CELL = 5.1e3
+# Gauss-Jordan in registers): rocprofv3 SQ_INSTS_VALU summed over a run / the run's simulated cells (profiles/r04_sgs_weights_valu_per_cell.txt)
+SGS_VALU_PER_CELL = 6.16e3
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4.25      # wave-instructions/s of the chip: 1024 SIMDs, one fp64-class instruction per 4.25 cycles
                                             # with four waves per SIMD (profiles/r02_valu_issue_rates.txt)
 
@@ -387,9 +387,9 @@ def measure_small_scale(H=64, n_chains=4, n_iter=400, cpu_iters=20):
                 "simulated_cells_per_s": cells_b / dt_b,
                 "roofline": {"bound": "valu_issue", "kernel": "sgs_weights_kernel", "achieved": ach / 1e9, "peak": VALU_ISSUE_PEAK / 1e9,
                              "unit": "G wave-instructions/s", "frac": ach / VALU_ISSUE_PEAK,
-                             "model": "simulated cells/s x 5.1 k vector wave-instructions per cell (ring search + 49-step Gauss-Jordan in "
-                                      "registers; rocprofv3 SQ_INSTS_VALU, profiles/r03_sgs_pmc_256chains.txt) against 1024 SIMDs x 2.4 GHz / 4.25 "
-                                      "cycles per fp64-class instruction; wall time of the whole iteration (8 launches), not of the kernel alone"}}}
+                             "model": "simulated cells/s x 6.16 k vector wave-instructions per cell (ring search + 49-step Gauss-Jordan in "
+                                      "registers; rocprofv3 SQ_INSTS_VALU, profiles/r04_sgs_weights_valu_per_cell.txt) against 1024 SIMDs x 2.4 GHz / 4.25 "
+                                      "cycles per fp64-class instruction; wall time of the whole iteration (6 launches on two streams), not of the kernel alone"}}}
 
 
 def measure_pcg64_mode(H=256, n_chains=1024, n_steps=2048):

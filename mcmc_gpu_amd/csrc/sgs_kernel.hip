@@ -137,7 +137,6 @@ struct SgsSearchLds {
   int32_t list_g[8][kSgsListCap];
   int32_t len[8];
   int32_t cum[8];
-  int32_t arcs[8];                        // the arcs of a ring that can hold cells of an open sector
   uint32_t cert[8][kSgsCertMax / 2];      // candidates of a sector by certification ring: 16-bit counters, two per word (a ring holds
                                           // at most 8 x 127 cells).  The kernel's occupancy is bounded by this structure's size.
   int32_t nb_g[kSgsMaxPts];
@@ -236,20 +235,6 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
   double radius = a.radius;
   int hw = a.hw;
   int n = 0;
-  // The sectors the cells strictly inside arc g can fall into (lane g < 8), whatever the ring: the directions of the arc's first and
-  // last inner cell on a huge ring bound them, and the sector number changes monotonically along a ring.
-  unsigned my_arcsec = 0;
-  {
-    constexpr int BIG = 1 << 20;
-    auto sec_of = [&](int gq, int p) { int di, dj; ring_cell(BIG, gq & 7, p, di, dj); return octant(-(double)di * sy, -(double)dj * sx); };
-    const int dirp = (((sec_of(2, 1) - sec_of(0, 1)) & 7) == 2) ? 1 : -1;
-    if (lane < 8) {
-      const int s_b = sec_of(lane, 1), s_e = sec_of(lane, BIG - 1);
-      const int steps = ((s_e - s_b) * dirp) & 7;
-      for (int i = 0; i < 8; ++i)
-        if (i <= steps) my_arcsec |= 1u << ((s_b + i * dirp) & 7);
-    }
-  }
   for (;;) {                                                     // radius widening (MCMC.py:150-156): usually one trip
     const int ilo = max(0, i0 - hw), ihi = min(H - 1, i0 + hw), jlo = max(0, j0 - hw), jhi = min(W - 1, j0 + hw);
     // cells towards smaller / larger row and column that the window holds
@@ -301,12 +286,9 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
       }
     };
     while (R < r_max && done_mask != 0xFFu) {
-      // one pass = rings R+1 .. R_hi: the 7 x 7 window first (rings 1-3 = 48 cells); then whole rings while most sectors are open,
-      // and only the arcs that can hold cells of an open sector -- of up to four rings at a time -- once few are
+      // one pass = rings R+1 .. R_hi: the 7 x 7 window first (rings 1-3 = 48 cells), then ring by ring
       const int R_lo = R + 1;
       int R_hi;
-      const unsigned am = (unsigned)(__ballot(lane < 8 && (my_arcsec & ~done_mask & 0xFFu) != 0u) & 0xFFull);
-      const int n_arc = __popc(am);
       if (R == 0) {
         R_hi = min(3, r_max);
         const int side_w = 2 * R_hi + 1, cells_in_pass = side_w * side_w;
@@ -315,7 +297,7 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
           const int di = t / side_w - R_hi, dj = t % side_w - R_hi;
           probe(di, dj, t < cells_in_pass && !(di == 0 && dj == 0));
         }
-      } else if (n_arc >= 5) {
+      } else {
         R_hi = R_lo;
         const int cells_in_pass = 8 * R_hi;
         const float inv_side = 1.0f / (float)(2 * R_hi);
@@ -327,28 +309,6 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(const SgsArgs a) {
           ring_cell(R_hi, 2 * side + (o >= R_hi ? 1 : 0), o >= R_hi ? o - R_hi : o, di, dj);
           probe(di, dj, t < cells_in_pass);
         }
-      } else {
-        // rows of a pass: per ring one row of the ring's 8 vertices (4 corners, 4 axis cells: they may fall into the sector on either
-        // side) and one row per open arc (the R' - 1 cells strictly between two vertices); row = arc slot * n_rings + ring, LW lanes per row
-        if (lane < 8 && ((am >> lane) & 1u)) L.arcs[__popc(am & ((1u << lane) - 1u))] = lane;
-        auto lanes_for = [&](int nr) { const int m = max(R_lo + nr - 2, 8); return m > 32 ? 64 : m > 16 ? 32 : m > 8 ? 16 : 8; };
-        int lg_nr = 0;
-        if (R_lo + 1 <= r_max && 2 * (n_arc + 1) * lanes_for(2) <= 64) lg_nr = 1;
-        if (R_lo + 3 <= r_max && 4 * (n_arc + 1) * lanes_for(4) <= 64) lg_nr = 2;
-        const int n_rings = 1 << lg_nr, LW = lanes_for(n_rings), lgw = 31 - __clz(LW);
-        R_hi = R_lo + n_rings - 1;
-        const int total_rows = (n_arc + 1) << lg_nr, rows_per_sub = 64 >> lgw;
-        __syncthreads();
-        for (int row0 = 0; row0 < total_rows; row0 += rows_per_sub)
-          for (int col0 = 0; col0 < max(R_hi - 1, 8); col0 += LW) {
-            const int row = row0 + (lane >> lgw), col = col0 + (lane & (LW - 1));
-            const int aslot = row >> lg_nr, Rr = R_lo + (row & (n_rings - 1));
-            const bool vertex = aslot == n_arc;
-            const int gq = vertex ? col : L.arcs[min(aslot, 7)];
-            int di, dj;
-            ring_cell(Rr, gq & 7, vertex ? 0 : col + 1, di, dj);
-            probe(di, dj, row < total_rows && (vertex ? col < 8 : col + 1 < Rr));
-          }
       }
       R = R_hi;
       bool fin = false;

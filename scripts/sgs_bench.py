@@ -12,6 +12,7 @@ if __name__ == "__main__":
     ap.add_argument('--iters', type=int, default=1000); ap.add_argument('--cpu-iters', type=int, default=0)
     ap.add_argument('--philox', action='store_true', help='Philox mode: the draws are made on the device')
     ap.add_argument('--light', action='store_true'); ap.add_argument('--no-transform', action='store_true')
+    ap.add_argument('--cells', action='store_true', help='also print the number of simulated cells (block cells without conditioning data)')
     ap.add_argument('--pcg64', action='store_true', help="the chains' own NumPy generator streams advanced on the device (replay mode's chain, no host draws)")
     a = ap.parse_args()
     from mcmc_gpu_amd import sgs, synthetic
@@ -26,6 +27,11 @@ if __name__ == "__main__":
     msg = (f"small-scale chain {H}x{H} ({'light' if a.light else 'driver'} config, transform {not a.no_transform}, "
            f"{'philox' if a.philox else 'pcg64' if a.pcg64 else 'replay'}), {a.chains} chains x {a.iters} iterations on the device: {t_dev:.2f} s = "
            f"{a.chains * a.iters / t_dev:.0f} chain-iterations/s ({a.iters / t_dev:.0f} it/s per chain, accept {np.mean([o[4].mean() for o in out]):.3f})")
+    if a.cells:
+        sys.path.insert(0, '.')
+        import bench
+        is_data = ~np.isnan(np.asarray(prob["cond_bed"]))
+        msg += f"; simulated cells of all chains and iterations: {bench._simulated_cells(out, is_data)}"
     if a.cpu_iters:
         import sgs_oracle as so
         v = ch.vario_param
