@@ -34,8 +34,9 @@ struct gsm_context {
   double* d_mathtab = nullptr;   // log / sincos table of the coefficient phase (math_tables.h)
   double* d_sgs_part_sum = nullptr; int32_t* d_sgs_part_bad = nullptr; int32_t* d_sgs_ticket = nullptr; size_t sgs_part_cap = 0;   // gsm_sgs_loss partial sums
   // gsm_sgs_blocks scratch: visiting ranks + one record per (chain, cell slot), see SgsArgs
-  void* d_sgs_rec[2] = {nullptr, nullptr}; size_t sgs_rec_cells[2] = {0, 0};     // record scratch; [1]: the odd iterations of an overlapped batch
-  hipStream_t sgs_side = nullptr; hipEvent_t sgs_ev[5] = {};                     // gsm_sgs_iterate's second stream (records of iteration j + 1 beside iteration j)
+  static constexpr int kSgsDepth = 8;                                            // sets of record scratch of an overlapped batch (iteration j uses set j mod depth)
+  void* d_sgs_rec[kSgsDepth] = {}; size_t sgs_rec_cells[kSgsDepth] = {};
+  hipStream_t sgs_side = nullptr; hipEvent_t sgs_ev[kSgsDepth + 2] = {};         // gsm_sgs_iterate's second stream (records of later iterations beside the current one)
   // gsm_sgs_iterate: the captured launch sequence of one batch (hipGraph), keyed by the bytes of its gsm_sgs_batch + n_iters
   int sgs_ktype = 0; const double* sgs_gmean = nullptr;        // gsm_sgs_set_kriging
   std::vector<char> sgs_graph_key; hipGraphExec_t sgs_graph_exec = nullptr; int sgs_graph_replays = 0;
@@ -145,7 +146,7 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_k2) hipFree(h->d_k2);
   if (h->d_mathtab) hipFree(h->d_mathtab);
   if (h->d_sgs_part_sum) { hipFree(h->d_sgs_part_sum); hipFree(h->d_sgs_part_bad); hipFree(h->d_sgs_ticket); }
-  for (int q = 0; q < 2; ++q) if (h->d_sgs_rec[q]) hipFree(h->d_sgs_rec[q]);
+  for (void* q : h->d_sgs_rec) if (q) hipFree(q);
   for (hipEvent_t e : h->sgs_ev) if (e) hipEventDestroy(e);
   if (h->sgs_side) hipStreamDestroy(h->sgs_side);
   if (h->sgs_graph_exec) hipGraphExecDestroy(h->sgs_graph_exec);
@@ -1178,10 +1179,19 @@ static int sgs_issue(gsm_handle h, const gsm_sgs_batch* b, int32_t n_iters, void
   const int64_t map = n * (int64_t)h->H * h->W;
   hipStream_t main_st = (hipStream_t)st;
   // The kriging weights of an iteration do not depend on the values of the grid, only on where values are: when the caller
-  // promises that every cell holds one (grid_finite), the records of iteration j + 1 (sgs_rank_kernel, sgs_weights_kernel) are made on a
-  // second stream while iteration j runs its value pass, transforms, loss and decision -- the longest kernel of an iteration leaves the
-  // critical path.  Two sets of record scratch, by the parity of the iteration.
+  // promises that every cell holds one (grid_finite), the records of the iterations ahead (sgs_rank_kernel, sgs_weights_kernel) are made on a
+  // second stream while the current iteration runs its value pass, transforms, loss and decision -- the longest kernel of an iteration
+  // leaves the critical path.  `depth` sets of record scratch (iteration j uses set j mod depth; <= 512 MiB in all): the second stream
+  // runs up to depth - 1 iterations ahead and waits for the main stream only every depth / 2 iterations -- a wait between two kernels of
+  // a stream costs ~10 us even when it is satisfied (rocprofv3 timeline of the two-set version), more than a quarter of the kernel it precedes.
   const bool overlap = b->grid_finite != 0 && n_iters > 1;
+  int depth = 1;
+  if (overlap) {
+    const size_t set_bytes = (size_t)n * (size_t)((b->max_cells + 63) & ~63) * (sizeof(SgsCellHdr) + 48 * sizeof(double2)) + (size_t)n * 4100;
+    depth = (int)std::min<size_t>(gsm_context::kSgsDepth, std::max<size_t>(2, ((size_t)512 << 20) / std::max<size_t>(set_bytes, 1)));
+    depth = std::min(depth, (int)n_iters);
+    if (depth >= 4) depth &= ~1;                                      // an even depth: the waits fall every depth / 2 iterations
+  }
   if (overlap && !h->sgs_side) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->sgs_side, hipStreamNonBlocking));
     for (hipEvent_t& e : h->sgs_ev) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1190,43 +1200,50 @@ static int sgs_issue(gsm_handle h, const gsm_sgs_batch* b, int32_t n_iters, void
     const int64_t base = b->cell_base ? b->cell_base[j] : 0;
     int rc = sgs_fill(h, a, b->next, b->zcond, b->windows + 4 * n * j, b->x_axis, b->y_axis, b->lag_cov, b->lag_mi, b->lag_mj, b->hw, b->radius,
                       b->num_points, b->sill, b->cell_off + b->cell_off_stride * j, b->cells + 2 * base, b->z + base, b->max_cells,
-                      "gsm_sgs_iterate", overlap ? (j & 1) : 0);
+                      "gsm_sgs_iterate", overlap ? (j % depth) : 0);
     if (rc) return rc;
     a.cell_cnt = b->cell_cnt ? b->cell_cnt + n * j : nullptr; a.trace = nullptr; a.nbr_trace = nullptr;
     a.defer = overlap ? 1 : 0;
     return GSM_OK;
   };
-  hipEvent_t* ev_w = h->sgs_ev;            // [2] records of parity p are complete
-  hipEvent_t* ev_s = h->sgs_ev + 2;        // [2] the value pass that read the records of parity p is over
-  SgsArgs a_cur{}, a_nxt{};
+  hipEvent_t* ev_w = h->sgs_ev;                               // [depth] the records of set s are complete
+  hipEvent_t ev_fork = h->sgs_ev[gsm_context::kSgsDepth];    // the draws are there
+  hipEvent_t ev_seq = h->sgs_ev[gsm_context::kSgsDepth + 1]; // the main stream has finished the value pass of some iteration
+  std::vector<SgsArgs> args(overlap ? n_iters : 1);
   int rc;
+  const int half = std::max(1, depth / 2);
+  int32_t issued = 0;                                         // iterations whose records have been enqueued on the second stream
+  auto enqueue_records = [&](int32_t upto) -> int {          // records of iterations issued .. upto - 1
+    for (; issued < upto; ++issued) {
+      HIPCHK(h, launch_sgs_weights(args[issued], args[issued].max_cells, h->sgs_side));
+      HIPCHK(h, hipEventRecord(ev_w[issued % depth], h->sgs_side));
+    }
+    return GSM_OK;
+  };
   if (overlap) {
-    SgsArgs t0{}, t1{};
-    if ((rc = fill(0, t0)) || (rc = fill(1, t1))) return rc;       // both sets of scratch exist before anything is enqueued
-    HIPCHK(h, hipEventRecord(h->sgs_ev[4], main_st));               // fork: whatever made the draws is on the main stream
-    HIPCHK(h, hipStreamWaitEvent(h->sgs_side, h->sgs_ev[4], 0));
-    a_cur = t0;
-    HIPCHK(h, launch_sgs_weights(a_cur, a_cur.max_cells, h->sgs_side));
-    HIPCHK(h, hipEventRecord(ev_w[0], h->sgs_side));
+    for (int32_t j = 0; j < n_iters; ++j)
+      if ((rc = fill(j, args[j]))) return rc;                 // every set of scratch exists before anything is enqueued
+    HIPCHK(h, hipEventRecord(ev_fork, main_st));              // fork: whatever made the draws is on the main stream
+    HIPCHK(h, hipStreamWaitEvent(h->sgs_side, ev_fork, 0));
+    if ((rc = enqueue_records(std::min<int32_t>(n_iters, depth - 1 > 0 ? depth - 1 : 1)))) return rc;
   }
   for (int32_t j = 0; j < n_iters; ++j) {
     const int32_t* win = b->windows + 4 * n * j;
     const double* u = b->u + n * j;
-    if (overlap && j + 1 < n_iters) {
-      if (j >= 1) HIPCHK(h, hipStreamWaitEvent(h->sgs_side, ev_s[(j + 1) & 1], 0));     // iteration j - 1 has read that set of records
-      if ((rc = fill(j + 1, a_nxt))) return rc;
-      HIPCHK(h, launch_sgs_weights(a_nxt, a_nxt.max_cells, h->sgs_side));
-      HIPCHK(h, hipEventRecord(ev_w[(j + 1) & 1], h->sgs_side));
-    }
     if (qt && (rc = gsm_qt_transform(h, b->qt_quantiles, b->qt_references, b->qt_n, b->cur, b->next, map, 0, st))) return rc;   // MCMC.py:1766
     if (overlap) {
-      HIPCHK(h, hipStreamWaitEvent(main_st, ev_w[j & 1], 0));
-      HIPCHK(h, launch_sgs_sequence(a_cur, main_st));
-      HIPCHK(h, hipEventRecord(ev_s[j & 1], main_st));
-      a_cur = a_nxt;
+      HIPCHK(h, hipStreamWaitEvent(main_st, ev_w[j % depth], 0));
+      HIPCHK(h, launch_sgs_sequence(args[j], main_st));
+      // set j mod depth is free again once this value pass is over: every `half` iterations the second stream is told so and
+      // takes the next `half` iterations' records (it then runs between depth - half and depth - 1 iterations ahead)
+      if ((j + 1) % half == 0 && issued < n_iters) {
+        HIPCHK(h, hipEventRecord(ev_seq, main_st));
+        HIPCHK(h, hipStreamWaitEvent(h->sgs_side, ev_seq, 0));
+        if ((rc = enqueue_records(std::min<int32_t>(n_iters, j + depth)))) return rc;
+      }
     } else {
-      if ((rc = fill(j, a_cur))) return rc;
-      HIPCHK(h, launch_sgs_blocks(a_cur, a_cur.max_cells, main_st));
+      if ((rc = fill(j, args[0]))) return rc;
+      HIPCHK(h, launch_sgs_blocks(args[0], args[0].max_cells, main_st));
     }
     if (b->windowed) {
       if ((rc = gsm_sgs_finish(h, b->cur, b->next, b->trend, b->energy, b->state, win, u, b->resampled, b->accept,
