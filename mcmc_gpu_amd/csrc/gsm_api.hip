@@ -36,7 +36,7 @@ struct gsm_context {
   // gsm_sgs_blocks scratch: visiting ranks + one record per (chain, cell slot), see SgsArgs
   static constexpr int kSgsDepth = 8;                                            // sets of record scratch of an overlapped batch (iteration j uses set j mod depth)
   void* d_sgs_rec[kSgsDepth] = {}; size_t sgs_rec_cells[kSgsDepth] = {};
-  hipStream_t sgs_side = nullptr; hipEvent_t sgs_ev[kSgsDepth + 2] = {};         // gsm_sgs_iterate's second stream (records of later iterations beside the current one)
+  hipStream_t sgs_side = nullptr, sgs_side2 = nullptr; hipEvent_t sgs_ev[kSgsDepth + 2] = {};         // gsm_sgs_iterate's second stream (records of later iterations beside the current one)
   // gsm_sgs_iterate: the captured launch sequence of one batch (hipGraph), keyed by the bytes of its gsm_sgs_batch + n_iters
   int sgs_ktype = 0; const double* sgs_gmean = nullptr;        // gsm_sgs_set_kriging
   std::vector<char> sgs_graph_key; hipGraphExec_t sgs_graph_exec = nullptr; int sgs_graph_replays = 0;
@@ -149,6 +149,7 @@ extern "C" int gsm_destroy(gsm_handle h) {
   for (void* q : h->d_sgs_rec) if (q) hipFree(q);
   for (hipEvent_t e : h->sgs_ev) if (e) hipEventDestroy(e);
   if (h->sgs_side) hipStreamDestroy(h->sgs_side);
+  if (h->sgs_side2) hipStreamDestroy(h->sgs_side2);
   if (h->sgs_graph_exec) hipGraphExecDestroy(h->sgs_graph_exec);
   if (h->d_pcg_tab) hipFree(h->d_pcg_tab);
   if (h->d_k2_off) hipFree(h->d_k2_off);
@@ -1194,8 +1195,12 @@ static int sgs_issue(gsm_handle h, const gsm_sgs_batch* b, int32_t n_iters, void
   }
   if (overlap && !h->sgs_side) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->sgs_side, hipStreamNonBlocking));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->sgs_side2, hipStreamNonBlocking));
     for (hipEvent_t& e : h->sgs_ev) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
+  // two record streams, even and odd iterations: with few chains a launch of sgs_weights_kernel leaves most of the chip idle
+  hipStream_t rec_st[2] = {h->sgs_side, depth >= 4 ? h->sgs_side2 : h->sgs_side};
+  bool must_wait[2] = {false, false};                         // the stream has not yet been told of the main stream's latest sync point
   auto fill = [&](int32_t j, SgsArgs& a) -> int {
     const int64_t base = b->cell_base ? b->cell_base[j] : 0;
     int rc = sgs_fill(h, a, b->next, b->zcond, b->windows + 4 * n * j, b->x_axis, b->y_axis, b->lag_cov, b->lag_mi, b->lag_mj, b->hw, b->radius,
@@ -1215,8 +1220,10 @@ static int sgs_issue(gsm_handle h, const gsm_sgs_batch* b, int32_t n_iters, void
   int32_t issued = 0;                                         // iterations whose records have been enqueued on the second stream
   auto enqueue_records = [&](int32_t upto) -> int {          // records of iterations issued .. upto - 1
     for (; issued < upto; ++issued) {
-      HIPCHK(h, launch_sgs_weights(args[issued], args[issued].max_cells, h->sgs_side));
-      HIPCHK(h, hipEventRecord(ev_w[issued % depth], h->sgs_side));
+      const int q = issued & 1;
+      if (must_wait[q]) { HIPCHK(h, hipStreamWaitEvent(rec_st[q], ev_seq, 0)); must_wait[q] = false; if (rec_st[0] == rec_st[1]) must_wait[q ^ 1] = false; }
+      HIPCHK(h, launch_sgs_weights(args[issued], args[issued].max_cells, rec_st[q]));
+      HIPCHK(h, hipEventRecord(ev_w[issued % depth], rec_st[q]));
     }
     return GSM_OK;
   };
@@ -1224,7 +1231,8 @@ static int sgs_issue(gsm_handle h, const gsm_sgs_batch* b, int32_t n_iters, void
     for (int32_t j = 0; j < n_iters; ++j)
       if ((rc = fill(j, args[j]))) return rc;                 // every set of scratch exists before anything is enqueued
     HIPCHK(h, hipEventRecord(ev_fork, main_st));              // fork: whatever made the draws is on the main stream
-    HIPCHK(h, hipStreamWaitEvent(h->sgs_side, ev_fork, 0));
+    HIPCHK(h, hipStreamWaitEvent(rec_st[0], ev_fork, 0));
+    if (rec_st[1] != rec_st[0] && n_iters > 1) HIPCHK(h, hipStreamWaitEvent(rec_st[1], ev_fork, 0));
     if ((rc = enqueue_records(std::min<int32_t>(n_iters, depth - 1 > 0 ? depth - 1 : 1)))) return rc;
   }
   for (int32_t j = 0; j < n_iters; ++j) {
@@ -1238,7 +1246,7 @@ static int sgs_issue(gsm_handle h, const gsm_sgs_batch* b, int32_t n_iters, void
       // takes the next `half` iterations' records (it then runs between depth - half and depth - 1 iterations ahead)
       if ((j + 1) % half == 0 && issued < n_iters) {
         HIPCHK(h, hipEventRecord(ev_seq, main_st));
-        HIPCHK(h, hipStreamWaitEvent(h->sgs_side, ev_seq, 0));
+        must_wait[0] = must_wait[1] = true;                    // (a stream waits when it next gets work: no wait is left dangling in a capture)
         if ((rc = enqueue_records(std::min<int32_t>(n_iters, j + depth)))) return rc;
       }
     } else {
