@@ -431,6 +431,7 @@ def test_graph_replay_of_a_batch_equals_the_eager_launches(monkeypatch, transfor
     the same launches one by one: every record must be identical bit for bit."""
     from mcmc_gpu_amd import sgs, synthetic
     res, replays = [], []
+    monkeypatch.setenv("GSM_SGS_BATCH", "32")          # (few chains default to batches of 128: too few full batches in 200 iterations)
     for flag in ("1", "0"):
         monkeypatch.setenv("GSM_SGS_GRAPH", flag)
         prob, ch = synthetic.sgs_template(32, transform=transform, light=True)
