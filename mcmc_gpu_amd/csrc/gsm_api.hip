@@ -36,6 +36,7 @@ struct gsm_context {
   // gsm_sgs_blocks scratch: visiting ranks + one record per (chain, cell slot), see SgsArgs
   static constexpr int kSgsDepth = 8;                                            // sets of record scratch of an overlapped batch (iteration j uses set j mod depth)
   void* d_sgs_rec[kSgsDepth] = {}; size_t sgs_rec_cells[kSgsDepth] = {};
+  double* d_sgs_next_acc = nullptr; size_t sgs_next_acc_cap = 0;                 // T(proposed) of every chain (sgs_loss_tail_kernel<true>)
   hipStream_t sgs_side = nullptr, sgs_side2 = nullptr; hipEvent_t sgs_ev[kSgsDepth + 2] = {};         // gsm_sgs_iterate's second stream (records of later iterations beside the current one)
   // gsm_sgs_iterate: the captured launch sequence of one batch (hipGraph), keyed by the bytes of its gsm_sgs_batch + n_iters
   int sgs_ktype = 0; const double* sgs_gmean = nullptr;        // gsm_sgs_set_kriging
@@ -148,6 +149,7 @@ extern "C" int gsm_destroy(gsm_handle h) {
   if (h->d_sgs_part_sum) { hipFree(h->d_sgs_part_sum); hipFree(h->d_sgs_part_bad); hipFree(h->d_sgs_ticket); }
   for (void* q : h->d_sgs_rec) if (q) hipFree(q);
   for (hipEvent_t e : h->sgs_ev) if (e) hipEventDestroy(e);
+  if (h->d_sgs_next_acc) hipFree(h->d_sgs_next_acc);
   if (h->sgs_side) hipStreamDestroy(h->sgs_side);
   if (h->sgs_side2) hipStreamDestroy(h->sgs_side2);
   if (h->sgs_graph_exec) hipGraphExecDestroy(h->sgs_graph_exec);
@@ -1235,10 +1237,29 @@ static int sgs_issue(gsm_handle h, const gsm_sgs_batch* b, int32_t n_iters, void
     if (rec_st[1] != rec_st[0] && n_iters > 1) HIPCHK(h, hipStreamWaitEvent(rec_st[1], ev_fork, 0));
     if ((rc = enqueue_records(std::min<int32_t>(n_iters, depth - 1 > 0 ? depth - 1 : 1)))) return rc;
   }
+  // with a transformer: both transforms of an iteration inside the tail launch where its tables and the map's parts fit
+  // (sgs_loss_tail_kernel<true>); the forward transform of the batch's first iteration is the stand-alone launch
+  // Measured (same box): 16 chains +4.8 %, 32 chains +9.5 %, 64 chains +4.1 %, 256 chains +2.9 %, 8 chains -7 %, 4 chains -19 % (a thread of the tail launch then makes ~8 transforms one after
+  // the other where the stand-alone launches make one per thread: with a few chains latency is what counts).  GSM_SGS_TAIL_QT=0 / 1 forces.
+  const char* tail_env = getenv("GSM_SGS_TAIL_QT");
+  const bool tail_qt_env = tail_env ? tail_env[0] != '0' : h->n_chains >= 12;
+  const bool tail_qt = qt && !b->windowed && tail_qt_env && h->have_static && sgs_tail_takes_qt(h->S, b->qt_n);
+  double qt_clip_min = 0.0, qt_clip_max = 0.0;
+  if (tail_qt) {
+    const double lo = 1e-7 - 2.220446049250313e-16;               // as gsm_qt_transform
+    qt_clip_min = ns::ndtri(lo); qt_clip_max = ns::ndtri(1.0 - lo);
+    if (h->sgs_next_acc_cap < (size_t)map) {
+      if (h->sgs_graph_exec) { hipGraphExecDestroy(h->sgs_graph_exec); h->sgs_graph_exec = nullptr; }
+      h->sgs_graph_key.clear();
+      if (h->d_sgs_next_acc) { hipFree(h->d_sgs_next_acc); h->d_sgs_next_acc = nullptr; h->sgs_next_acc_cap = 0; }
+      HIPCHK(h, hipMalloc(&h->d_sgs_next_acc, (size_t)map * sizeof(double)));
+      h->sgs_next_acc_cap = (size_t)map;
+    }
+  }
   for (int32_t j = 0; j < n_iters; ++j) {
     const int32_t* win = b->windows + 4 * n * j;
     const double* u = b->u + n * j;
-    if (qt && (rc = gsm_qt_transform(h, b->qt_quantiles, b->qt_references, b->qt_n, b->cur, b->next, map, 0, st))) return rc;   // MCMC.py:1766
+    if (qt && (!tail_qt || j == 0) && (rc = gsm_qt_transform(h, b->qt_quantiles, b->qt_references, b->qt_n, b->cur, b->next, map, 0, st))) return rc;   // MCMC.py:1766
     if (overlap) {
       HIPCHK(h, hipStreamWaitEvent(main_st, ev_w[j % depth], 0));
       HIPCHK(h, launch_sgs_sequence(args[j], main_st));
@@ -1258,14 +1279,15 @@ static int sgs_issue(gsm_handle h, const gsm_sgs_batch* b, int32_t n_iters, void
                                b->loss_rec ? b->loss_rec + j : nullptr, b->acc_rec ? b->acc_rec + j : nullptr, n_iters, st))) return rc;
       continue;
     }
-    if (qt && (rc = gsm_qt_transform(h, b->qt_quantiles, b->qt_references, b->qt_n, b->next, b->proposed, map, 1, st))) return rc;  // MCMC.py:1777
+    if (qt && !tail_qt && (rc = gsm_qt_transform(h, b->qt_quantiles, b->qt_references, b->qt_n, b->next, b->proposed, map, 1, st))) return rc;  // MCMC.py:1777
     // loss of the proposal, decision and commit (gsm_sgs_loss, gsm_sgs_decide, gsm_sgs_commit_map / gsm_sgs_commit) in one launch
     if (!h->have_static) return fail(h, GSM_E_STATE, "gsm_sgs_iterate: call gsm_set_static first");
     if (h->f32_state) return fail(h, GSM_E_UNSUPPORTED, "gsm_sgs_iterate: fp64 beds only");
     if ((rc = sgs_parts_ensure(h))) return rc;
     HIPCHK(h, launch_sgs_loss_tail(h->S, h->n_chains, b->trend, h->d_sgs_part_sum, h->d_sgs_part_bad, h->d_sgs_ticket, b->loss, b->bad, u,
                                    b->loss_prev, b->accept, b->loss_rec ? b->loss_rec + j : nullptr, b->acc_rec ? b->acc_rec + j : nullptr,
-                                   n_iters, qt ? 1 : 2, b->cur, qt ? b->proposed : b->next, b->resampled, win, main_st));
+                                   n_iters, qt ? 1 : 2, b->cur, qt ? b->proposed : b->next, b->resampled, win, main_st,
+                                   tail_qt ? b->qt_quantiles : nullptr, b->qt_references, b->qt_n, qt_clip_min, qt_clip_max, b->next, h->d_sgs_next_acc));
   }
   return GSM_OK;
 }

@@ -239,7 +239,9 @@ hipError_t launch_sgs_loss(const StaticFields& S, int n_chains, const double* be
 hipError_t launch_sgs_loss_tail(const StaticFields& S, int n_chains, const double* trend, double* part_sum, int32_t* part_bad, int32_t* ticket,
                                 double* loss, int32_t* bad, const double* u, double* loss_prev, uint8_t* accept, double* loss_rec,
                                 uint8_t* acc_rec, int64_t rec_stride, int mode, double* cur, double* beds, uint32_t* resampled,
-                                const int32_t* win, hipStream_t st);
+                                const int32_t* win, hipStream_t st, const double* qt_q = nullptr, const double* qt_ref = nullptr, int qt_n = 0,
+                                double clip_min = 0.0, double clip_max = 0.0, double* next = nullptr, double* next_acc = nullptr);
+bool sgs_tail_takes_qt(const StaticFields& S, int nq);
 hipError_t launch_sgs_state_init(const StaticFields& S, int n_chains, const double* beds, const double* trend, double* energy, double* state,
                                  hipStream_t st);
 hipError_t launch_sgs_finish(const StaticFields& S, int n_chains, double* cur, double* next, const double* trend, double* energy, double* state,

@@ -619,9 +619,10 @@ hipError_t launch_sgs_blocks(const SgsArgs& a, int launch_cells, hipStream_t st)
 // Several workgroups per chain (a chain's grid is split into `parts` contiguous ranges of cells), then one thread per chain
 // adds the parts in order: with one workgroup per chain a 256 x 256 grid kept 16 CUs busy for 0.19 ms per iteration.
 // one part of a chain's map by the 256 threads of a workgroup; thread 0 returns the part's sum and bad-cell count
-__device__ __forceinline__ void sgs_loss_part(const StaticFields& S, const double* bed, const double* trend, int g_lo, int g_hi, int tid,
+// (bed[q - off] is cell q of the chain's map: off != 0 when `bed` is a tile of the map in LDS)
+__device__ __forceinline__ void sgs_loss_part(const StaticFields& S, const double* bed, const int off, const double* trend, int g_lo, int g_hi, int tid,
                                               double* red, int* redb, double& sum_out, int& bad_out) {
-  auto bed_at = [&](int rr, int cc) { const int q = rr * S.W + cc; return trend ? bed[q] + trend[q] : bed[q]; };
+  auto bed_at = [&](int rr, int cc) { const int q = rr * S.W + cc; return trend ? bed[q - off] + trend[q] : bed[q - off]; };
   double hi = 0.0, lo = 0.0;
   int nbad = 0;
   for (int g = g_lo + tid; g < g_hi; g += 256) {
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(256) void sgs_loss_kernel(const StaticFields S, con
   const int plane = S.H * S.W;
   const int per = (plane + parts - 1) / parts, g_lo = part * per, g_hi = min(plane, g_lo + per);
   double t; int nb;
-  sgs_loss_part(S, beds + (size_t)chain * plane, trend, g_lo, g_hi, tid, red, redb, t, nb);
+  sgs_loss_part(S, beds + (size_t)chain * plane, 0, trend, g_lo, g_hi, tid, red, redb, t, nb);
   if (tid == 0) { part_sum[chain * parts + part] = t; part_bad[chain * parts + part] = nb; }
 }
 __global__ __launch_bounds__(64) void sgs_loss_finish_kernel(int n_chains, int parts, double two_sigma2, const double* __restrict__ part_sum,
@@ -973,17 +974,46 @@ struct SgsTailArgs {
   const double* trend; int parts; double* part_sum; int32_t* part_bad; int32_t* ticket;
   double* loss; int32_t* bad; const double* u; double* loss_prev; uint8_t* accept; double* loss_rec; uint8_t* acc_rec; int64_t rec_stride;
   int mode; double* cur; double* beds; uint32_t* resampled; const int32_t* win;
+  // QT: the two normal-score transforms of an iteration in this launch as well (see below)
+  const double* qt_q; const double* qt_ref; int qt_n; double clip_min, clip_max; double* next; double* next_acc;
 };
+// QT (mode 1 only; tables of <= kTailQt entries, parts of <= kTailTile cells with their two halo rows): `beds` (the proposed plane) is not
+// read but MADE here -- every workgroup inverse-transforms its part of `next` and one row either side into LDS (qt_kernel's arithmetic:
+// the same functions on the same table values), stores its own part, and scores from LDS -- and so is the NEXT iteration's forward transform:
+// the part's T(proposed) goes to `next_acc`; the chain's last workgroup copies it to `next` if the proposal is accepted (cur = proposed,
+// so T(cur) = T(proposed)) and otherwise re-transforms the block window of `cur` (everything else of `next` still is T(cur)).  Two
+// elementwise launches per iteration less (MCMC.py:1766, :1777 stay where they are in the arithmetic).
+constexpr int kTailQt = 1024, kTailTile = 2048;
+template <bool QT>
 __global__ __launch_bounds__(256) void sgs_loss_tail_kernel(const StaticFields S, const SgsTailArgs a) {
   __shared__ double red[8];
   __shared__ int redb[4];
   __shared__ int s_last, s_acc;
+  __shared__ double qtab[QT ? 2 * kTailQt : 1];
+  __shared__ double tile[QT ? kTailTile : 1];
   const int chain = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
   const int H = S.H, W = S.W, plane = H * W, parts = a.parts;
   const int per = (plane + parts - 1) / parts, g_lo = part * per, g_hi = min(plane, g_lo + per);
   const size_t base = (size_t)chain * plane;
+  const double* bed = a.beds + base;
+  int off = 0;
+  if (QT) {
+    for (int i = tid; i < a.qt_n; i += 256) { qtab[i] = a.qt_q[i]; qtab[kTailQt + i] = a.qt_ref[i]; }
+    __syncthreads();
+    const int lo_h = max(0, g_lo - W), hi_h = min(plane, g_hi + W);
+    for (int idx = lo_h + tid; idx < hi_h; idx += 256) {
+      const double v = ns::qt_inverse(a.next[base + idx], qtab, qtab + kTailQt, a.qt_n);
+      tile[idx - lo_h] = v;
+      if (idx >= g_lo && idx < g_hi) {
+        a.beds[base + idx] = v;
+        a.next_acc[base + idx] = ns::qt_forward(v, qtab, qtab + kTailQt, a.qt_n, a.clip_min, a.clip_max);
+      }
+    }
+    __syncthreads();
+    bed = tile; off = lo_h;
+  }
   double t; int nb;
-  sgs_loss_part(S, a.beds + base, a.trend, g_lo, g_hi, tid, red, redb, t, nb);
+  sgs_loss_part(S, bed, off, a.trend, g_lo, g_hi, tid, red, redb, t, nb);
   if (tid == 0) {
     __hip_atomic_store(&a.part_sum[chain * parts + part], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&a.part_bad[chain * parts + part], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1020,7 +1050,19 @@ __global__ __launch_bounds__(256) void sgs_loss_tail_kernel(const StaticFields S
   const bool acc = s_acc != 0;
   const int r0 = a.win[4 * chain], r1 = a.win[4 * chain + 1], c0 = a.win[4 * chain + 2], c1 = a.win[4 * chain + 3];
   const int ww = c1 - c0, n = (r1 - r0) * ww;
-  if (a.mode == 1) {
+  if (QT) {
+    // the other workgroups' parts of `beds` and `next_acc` were stored before their tickets (release); thread 0 took the last ticket (acquire)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (acc) {
+      for (int p = tid; p < plane; p += 256) { a.cur[base + p] = a.beds[base + p]; a.next[base + p] = a.next_acc[base + p]; }
+      for (int p = tid; p < n; p += 256) a.resampled[base + (size_t)(r0 + p / ww) * W + c0 + p % ww] += 1u;
+    } else {
+      for (int p = tid; p < n; p += 256) {
+        const size_t q = base + (size_t)(r0 + p / ww) * W + c0 + p % ww;
+        a.next[q] = ns::qt_forward(a.cur[q], qtab, qtab + kTailQt, a.qt_n, a.clip_min, a.clip_max);
+      }
+    }
+  } else if (a.mode == 1) {
     if (!acc) return;
     for (int p = tid; p < plane; p += 256) a.cur[base + p] = a.beds[base + p];
     for (int p = tid; p < n; p += 256) a.resampled[base + (size_t)(r0 + p / ww) * W + c0 + p % ww] += 1u;
@@ -1032,15 +1074,26 @@ __global__ __launch_bounds__(256) void sgs_loss_tail_kernel(const StaticFields S
     }
   }
 }
+// whether the tail launch can make the two transforms of an iteration as well (sgs_loss_tail_kernel<true>)
+bool sgs_tail_takes_qt(const StaticFields& S, int nq) {
+  const int plane = S.H * S.W, parts = sgs_loss_parts(S), per = (plane + parts - 1) / parts;
+  return nq >= 1 && nq <= kTailQt && per + 2 * S.W <= kTailTile;
+}
 hipError_t launch_sgs_loss_tail(const StaticFields& S, int n_chains, const double* trend, double* part_sum, int32_t* part_bad, int32_t* ticket,
                                 double* loss, int32_t* bad, const double* u, double* loss_prev, uint8_t* accept, double* loss_rec,
                                 uint8_t* acc_rec, int64_t rec_stride, int mode, double* cur, double* beds, uint32_t* resampled,
-                                const int32_t* win, hipStream_t st) {
+                                const int32_t* win, hipStream_t st, const double* qt_q, const double* qt_ref, int qt_n, double clip_min,
+                                double clip_max, double* next, double* next_acc) {
   SgsTailArgs a;
   a.trend = trend; a.parts = sgs_loss_parts(S); a.part_sum = part_sum; a.part_bad = part_bad; a.ticket = ticket;
   a.loss = loss; a.bad = bad; a.u = u; a.loss_prev = loss_prev; a.accept = accept; a.loss_rec = loss_rec; a.acc_rec = acc_rec;
   a.rec_stride = rec_stride; a.mode = mode; a.cur = cur; a.beds = beds; a.resampled = resampled; a.win = win;
-  hipLaunchKernelGGL(sgs_loss_tail_kernel, dim3(n_chains, a.parts), dim3(256), 0, st, S, a);
+  a.qt_q = qt_q; a.qt_ref = qt_ref; a.qt_n = qt_n; a.clip_min = clip_min; a.clip_max = clip_max; a.next = next; a.next_acc = next_acc;
+  if (qt_q) {
+    if (mode != 1 || !sgs_tail_takes_qt(S, qt_n) || !next || !next_acc) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sgs_loss_tail_kernel<true>, dim3(n_chains, a.parts), dim3(256), 0, st, S, a);
+  } else
+    hipLaunchKernelGGL(sgs_loss_tail_kernel<false>, dim3(n_chains, a.parts), dim3(256), 0, st, S, a);
   return hipGetLastError();
 }
 

@@ -12,7 +12,7 @@ a = ap.parse_args()
 from mcmc_gpu_amd import sgs, synthetic
 res = []
 for overlap in ('1', '0'):
-    os.environ['GSM_SGS_OVERLAP'] = overlap; os.environ['GSM_SGS_DRAW_AHEAD'] = overlap
+    os.environ['GSM_SGS_OVERLAP'] = overlap; os.environ['GSM_SGS_DRAW_AHEAD'] = overlap; os.environ['GSM_SGS_TAIL_QT'] = overlap
     prob, ch = synthetic.sgs_template(a.grid)
     beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(a.chains)]
     rngs = [np.random.default_rng(900 + i) for i in range(a.chains)]

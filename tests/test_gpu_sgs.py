@@ -456,9 +456,10 @@ def test_records_made_ahead_and_draws_made_ahead_change_nothing(monkeypatch, tra
     generators' final states are identical bit for bit to the launches in the reference's order (MCMC.py:1741-1822)."""
     from mcmc_gpu_amd import sgs, synthetic
     res = []
-    for overlap, ahead in (("1", "1"), ("0", "0"), ("1", "0")):
+    for overlap, ahead, tail_qt in (("1", "1", "1"), ("0", "0", "0"), ("1", "0", "0"), ("0", "1", "1")):
         monkeypatch.setenv("GSM_SGS_OVERLAP", overlap)
         monkeypatch.setenv("GSM_SGS_DRAW_AHEAD", ahead)
+        monkeypatch.setenv("GSM_SGS_TAIL_QT", tail_qt)         # both transforms of an iteration inside the tail launch, or stand-alone
         prob, ch = synthetic.sgs_template(48 if not light else 32, transform=transform, light=light)
         beds = [prob["bed"] + np.random.default_rng(40 + i).normal(0, 3, prob["bed"].shape) for i in range(3)]
         rngs = [np.random.default_rng(170 + i) for i in range(3)]
