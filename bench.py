@@ -389,7 +389,7 @@ def measure_small_scale(H=64, n_chains=4, n_iter=400, cpu_iters=20):
                              "unit": "G wave-instructions/s", "frac": ach / VALU_ISSUE_PEAK,
                              "model": "simulated cells/s x 6.16 k vector wave-instructions per cell (ring search + 49-step Gauss-Jordan in "
                                       "registers; rocprofv3 SQ_INSTS_VALU, profiles/r04_sgs_weights_valu_per_cell.txt) against 1024 SIMDs x 2.4 GHz / 4.25 "
-                                      "cycles per fp64-class instruction; wall time of the whole iteration (6 launches on two streams), not of the kernel alone"}}}
+                                      "cycles per fp64-class instruction; wall time of the whole iteration (ranks + weights on the record streams; value pass and one launch for transforms, loss, decision and commit on the main stream), not of the kernel alone"}}}
 
 
 def measure_pcg64_mode(H=256, n_chains=1024, n_steps=2048):
