@@ -336,7 +336,17 @@ __device__ __forceinline__ void dft_stage1(const int w, const int lane, const Pr
       Unit A = setup(j), B = setup(j + 1);
       v4f64 cA = {0.0, 0.0, 0.0, 0.0}, sA = cA, cB = cA, sB = cA;
       if (A.on && B.on) {
-        for (int k0 = 0; k0 < KR; k0 += 4) {
+        {
+          const v4f64 Z = {0.0, 0.0, 0.0, 0.0};
+          double a1, a2, b1, b2, a3, a4, b3, b4;
+          fetch(A, 0, a1, a2, b1, b2);
+          fetch(B, 0, a3, a4, b3, b4);
+          cA = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, Z, 0, 0, 0);
+          sA = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, Z, 0, 0, 0);
+          cB = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, Z, 0, 0, 0);
+          sB = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, b4, Z, 0, 0, 0);
+        }
+        for (int k0 = 4; k0 < KR; k0 += 4) {
           double a1, a2, b1, b2, a3, a4, b3, b4;
           fetch(A, k0, a1, a2, b1, b2);
           fetch(B, k0, a3, a4, b3, b4);
@@ -472,7 +482,17 @@ __device__ __forceinline__ void dft_stage2(const int w, const int lane, const Pr
       Tile A = setup(j), B = setup(j + 1);
       v4f64 eA = {0.0, 0.0, 0.0, 0.0}, oA = eA, eB = eA, oB = eA;
       if (A.on && B.on) {
-        for (int k0 = 0; k0 < Kc; k0 += 4) {
+        {
+          const v4f64 Z = {0.0, 0.0, 0.0, 0.0};
+          double a1, a2, b1, b2, a3, a4, b3, b4;
+          fetch(A, 0, a1, a2, b1, b2);
+          fetch(B, 0, a3, a4, b3, b4);
+          eA = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, Z, 0, 0, 0);
+          oA = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, Z, 0, 0, 0);
+          eB = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, Z, 0, 0, 0);
+          oB = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, b4, Z, 0, 0, 0);
+        }
+        for (int k0 = 4; k0 < Kc; k0 += 4) {
           double a1, a2, b1, b2, a3, a4, b3, b4;
           fetch(A, k0, a1, a2, b1, b2);
           fetch(B, k0, a3, a4, b3, b4);
