@@ -467,6 +467,10 @@ int gsm_debug_normals(uint64_t seed, int64_t step, uint32_t stream_id, uint32_t 
  * the same inline function.  Checked against the Random123 known-answer vectors. */
 int gsm_philox_selftest(const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4);
 
+/* sizeof of a struct of this header as the library was compiled: which = 0 gsm_rf_params, 1 gsm_sgs_batch, 2 gsm_vario; -1 for any other value.
+ * For bindings that restate the structs (ctypes, cgo ...): a mismatch is a layout error that would otherwise corrupt silently. */
+int gsm_struct_size(int32_t which);
+
 #ifdef __cplusplus
 }
 #endif

@@ -226,6 +226,10 @@ def load() -> C.CDLL:
     lib.gsm_debug_stream_copy.argtypes = [vp, vp, i64, vp]
     lib.gsm_debug_normals.argtypes = [C.c_uint64, i64, C.c_uint32, C.c_uint32, i32, vp, vp]
     lib.gsm_philox_selftest.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.gsm_struct_size.argtypes = [i32]
+    for which, cls in ((0, RfParams), (1, SgsBatch), (2, Vario)):       # the ctypes restatements of the header's structs have the library's layout
+        if lib.gsm_struct_size(which) != C.sizeof(cls):
+            raise RuntimeError(f"{cls.__name__}: ctypes size {C.sizeof(cls)} != library's {lib.gsm_struct_size(which)} (include/gsm.h changed?)")
     for name in declared_symbols():
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch
         if name not in ("gsm_version", "gsm_last_error"):

@@ -1338,6 +1338,10 @@ extern "C" int gsm_sgs_iterate(gsm_handle h, const gsm_sgs_batch* b, int32_t n_i
 
 extern "C" int gsm_sgs_graph_replays(gsm_handle h) { return h ? h->sgs_graph_replays : GSM_E_ARG; }
 
+extern "C" int gsm_struct_size(int32_t which) {
+  return which == 0 ? (int)sizeof(gsm_rf_params) : which == 1 ? (int)sizeof(gsm_sgs_batch) : which == 2 ? (int)sizeof(gsm_vario) : -1;
+}
+
 extern "C" int gsm_min_dist_from_mask(gsm_handle h, const double* xx, const double* yy, const uint8_t* mask,
                                       double* dist, void* stream) {
   if (!h) return GSM_E_ARG;

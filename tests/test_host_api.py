@@ -30,6 +30,18 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert "gfx950" in out
 
 
+def test_struct_restatements_have_the_librarys_layout():
+    """The ctypes mirrors of include/gsm.h's structs against sizeof in the compiled library (gsm_struct_size): a field added on one side
+    only would shift every later field silently.  (load() makes the same check and refuses a mismatching library.)"""
+    import ctypes as C
+    from mcmc_gpu_amd import _lib
+    lib = _lib.load()
+    assert lib.gsm_struct_size(0) == C.sizeof(_lib.RfParams)
+    assert lib.gsm_struct_size(1) == C.sizeof(_lib.SgsBatch)
+    assert lib.gsm_struct_size(2) == C.sizeof(_lib.Vario)
+    assert lib.gsm_struct_size(99) == -1
+
+
 def test_create_without_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():
