@@ -14,7 +14,7 @@ def build(name, patch):
     if src.exists(): shutil.rmtree(src)
     shutil.copytree(_lib.CSRC, src)
     # keep the relative include of ../../include/gsm.h working
-    for f in src.glob('*.h'):
+    for f in list(src.glob('*.h')) + list(src.glob('*.hip')):
         t = f.read_text().replace('"../../include/gsm.h"', '"' + str(_lib.HEADER) + '"'); f.write_text(t)
     patch(src)
     objs = []; procs = []
