@@ -60,3 +60,47 @@ def test_standard_tables_run_the_strip_kernels():
         eng, *_ = make_engine(H, 2)
         assert eng.strip_active()
         eng.close()
+
+
+_CHILD_WIDE = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + '/oracle'); sys.path.insert(0, {root!r} + '/tests')
+import mcmc_oracle as orc
+from mcmc_gpu_amd.engine import GsmEngine
+H, W, n = {H}, {W}, {n}
+prob = orc.synthetic_problem(H, W)
+res = prob["resolution"]
+pairs = orc.block_pairs({bw0}, {bw1}, {bh0}, {bh1})          # (bw, bh) columns, MCMC.py:576-579
+lp = [2, 0, 6, 1]
+masks = orc.edge_masks(pairs, lp, 49900.0, res)
+w = orc.crf_weight(prob["xx"], prob["yy"], prob["data_mask"], lp, 49900.0)
+ones = np.full(prob["region_mask"].shape, 1)
+eng = GsmEngine(H, W, 3)
+eng.set_static(prob["surf"], prob["velx"], prob["vely"], prob["dhdt"], prob["smb"], w, ones, ones, res, 5.0)
+eng.set_blocks(pairs, masks)
+eng.set_centres(ones)                                          # whole-map updates: windows clipped on every side
+rfp = orc.standard_rf_params(); rfp.resolution = res
+eng.set_state(np.stack([orc.chain_initial_bed(prob, c) for c in range(3)]))
+loss, acc, blk = eng.run_philox(n, 3, [21, 22, 23], rfp, batch=n)
+np.savez({out!r}, strip=int(eng.strip_active()), loss=loss, acc=acc, blk=blk, beds=eng.beds.cpu().numpy(),
+         energy=eng.energy.cpu().numpy(), res=eng.resampled.cpu().numpy())
+"""
+
+
+def test_strip_kernels_equal_flux_tile_kernels_wide_blocks_on_an_oblong_grid(tmp_path):
+    """Blocks 20 - 110 cells wide and 20 - 50 tall on a 128 x 192 grid, whole-map updates: every strip decomposition up to two
+    64-lane column groups (strip::config: 64-, 16-, 32- and 2 x 64-lane strips), H != W, most windows clipped."""
+    outs = {}
+    for strip in (1, 0):
+        out = str(tmp_path / f"wide_{strip}.npz")
+        code = _CHILD_WIDE.format(root=str(ROOT), H=128, W=192, n=80, bw0=20, bw1=110, bh0=20, bh1=50, out=out)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSM_STRIP=str(strip)), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[strip] = np.load(out)
+    a, b = outs[1], outs[0]
+    assert int(a["strip"]) == 1 and int(b["strip"]) == 0
+    widths = set(int(x) for x in a["blk"][..., 3].ravel())
+    assert max(widths) > 90 and min(widths) <= 62                 # the two-group 64-lane strips and the one-group ones both ran
+    for k in ("acc", "blk", "beds", "energy", "res"):
+        assert np.array_equal(a[k], b[k]), k
+    np.testing.assert_allclose(a["loss"], b["loss"], rtol=1e-12)
