@@ -324,7 +324,10 @@ extern "C" int gsm_set_blocks(gsm_handle h, int32_t n_sizes, const int32_t* bh, 
     const int ncol = w / 2 + 1, Kc = (ncol + 3) & ~3, M1 = (ncol + 15) & ~15;
     m1max = std::max(m1max, M1); kcmax = std::max(kcmax, Kc);
     tiles_max = std::max(tiles_max, (N1 / 16) * (M1 / 16));
-    h->prop_tiles1 = std::max(h->prop_tiles1, (M1 / 16) * (NR / 16));
+    // stage-1 work units = 2 x this: (output tile, re | im) of the direct sums (odd heights), twice that over the half range of y for
+    // the parity-split sums of even heights (proposal_device.h: dft_stage1)
+    const int NRh = ((n / 2) / 2 + 16) & ~15;
+    h->prop_tiles1 = std::max(h->prop_tiles1, (n & 1) ? (M1 / 16) * (NR / 16) : 2 * (M1 / 16) * (NRh / 16));
     if (g_off[w] < 0) {
       g_off[w] = (int32_t)tb.size();
       tb.resize(tb.size() + (size_t)2 * Kc * M1, 0.0);

@@ -180,6 +180,10 @@ struct PropGeom {
   int N1;   // stage-2 M  (y), multiple of 16
   int SX, ST;
   uint32_t q_mt, q_mt2;   // tile_magic of M1 / 16 (stage-1 tile columns) and N1 / 16 (stage-2 tile rows)
+  // even block heights (every table of the reference: MCMC.py:576-579 rounds the sizes to even): stage 1 is split by the parity of ky
+  int hq;   // hh / 2: the half-sums are evaluated for y in [0, hq]; hh - y mirrors them
+  int NRh;  // ... padded to a multiple of 16
+  int Ke;   // terms of a half-sum, padded to a multiple of 4
 };
 __device__ __forceinline__ PropGeom prop_geom(const ProposeArgs& a, int bh, int bw) {
   PropGeom g;
@@ -190,6 +194,7 @@ __device__ __forceinline__ PropGeom prop_geom(const ProposeArgs& a, int bh, int 
   g.N1 = (bh + 15) & ~15;
   g.SX = a.lds_sx; g.ST = a.lds_st;
   g.q_mt = tile_magic(g.M1 >> 4); g.q_mt2 = tile_magic(g.N1 >> 4);
+  g.hq = g.hh >> 1; g.NRh = (g.hq + 16) & ~15; g.Ke = (g.hq + 4) & ~3;
   return g;
 }
 
@@ -305,6 +310,68 @@ __device__ __forceinline__ void dft_stage1(const int w, const int lane, const Pr
   const int l15 = lane & 15, l4 = lane >> 4;
   const int n_mt = g.M1 >> 4, n_nt = NR >> 4;
   const int n_t1 = n_mt * n_nt;
+  if (!(g.bh & 1)) {
+    // ---- even block height n = 2 h: the sums split by the parity of ky (radix 2) ----------------------------------------------
+    //   U[y] = Ue[y] + Uo[y], U[h - y] = Ue[y] - Uo[y];  V[y] = Ve[y] + Vo[y], V[h - y] = -Ve[y] + Vo[y]   (dft_tt_write)
+    // with Ue / Ve over ky = 2 m and Uo / Vo over ky = 2 m + 1, each evaluated for y in [0, h / 2] only: half the products of the
+    // direct sums.  A work unit is one parity of one (output tile, re | im) pair; the two parities of a pair are units j, j + 1
+    // of the same wave and run through the K loop together (four independent MFMAs per K step).  Row 2 (k0 + l4) (+ 1) of a
+    // plane may lie beyond its zero padding in the last K step only: that step reads a clamped row and zeroes the operand.
+    const int n_pairs = 2 * n_mt * (g.NRh >> 4);
+    const int Ke = g.Ke, bh = g.bh;
+    const uint32_t n8 = 8u * (uint32_t)bh;
+    const double* __restrict__ T2 = (TABMODE == 1) ? tabA : (TABMODE == 0 ? a.tables + sc.fy_off : nullptr);      // [cos: KR x NR][sin: KR x NR]
+#pragma unroll
+    for (int j = 0; j < UPW; j += 2) {
+      const int pq = w + (j >> 1) * NW;
+      v4f64 cE = {0.0, 0.0, 0.0, 0.0}, sE = cE, cO = cE, sO = cE;
+      if ((j + 1 < UPW) && pq < n_pairs && !(a.dbg & 2)) {
+        const int t = pq >> 1;
+        const int nt = tile_div(t, g.q_mt), mt = t - nt * n_mt;
+        const double* __restrict__ Ac = (pq & 1) ? Pi : Pr;
+        const double* __restrict__ As = (pq & 1) ? Mr : Mi;
+        const int col = 16 * mt + l15, y = 16 * nt + l15;
+        uint32_t mE = 0u, mO = 0u, d8 = 0u;
+        if (TABMODE == 2) {
+          const uint32_t yy = mod_magic((uint32_t)y, (uint32_t)bh, sc.m_bh);
+          mE = 8u * mod_magic((uint32_t)(2 * l4) * yy, (uint32_t)bh, sc.m_bh);
+          mO = 8u * mod_magic((uint32_t)(2 * l4 + 1) * yy, (uint32_t)bh, sc.m_bh);
+          d8 = 8u * mod_magic(8u * yy, (uint32_t)bh, sc.m_bh);
+        }
+        auto kstep = [&](const int k0, const bool last) {
+          int rE = 2 * (k0 + l4), rO = rE + 1;
+          const bool vE = rE < KR, vO = rO < KR;
+          if (last) { rE = min(rE, KR - 1); rO = min(rO, KR - 1); }
+          double aEc = Ac[rE * SX + col], aEs = As[rE * SX + col], aOc = Ac[rO * SX + col], aOs = As[rO * SX + col];
+          if (last) {
+            if (!vE) { aEc = 0.0; aEs = 0.0; }
+            if (!vO) { aOc = 0.0; aOs = 0.0; }
+          }
+          double bEc, bEs, bOc, bOs;
+          if (TABMODE == 2) {
+            const char* tE = (const char*)tabA + mE;
+            const char* tO = (const char*)tabA + mO;
+            bEc = *(const double*)tE; bEs = *(const double*)(tE + 8 * kT1S);
+            bOc = *(const double*)tO; bOs = *(const double*)(tO + 8 * kT1S);
+            mE += d8; mE = min(mE, mE - n8);
+            mO += d8; mO = min(mO, mO - n8);
+          } else {
+            bEc = T2[rE * NR + y]; bEs = T2[KR * NR + rE * NR + y];
+            bOc = T2[rO * NR + y]; bOs = T2[KR * NR + rO * NR + y];
+          }
+          cE = __builtin_amdgcn_mfma_f64_16x16x4f64(aEc, bEc, cE, 0, 0, 0);
+          sE = __builtin_amdgcn_mfma_f64_16x16x4f64(aEs, bEs, sE, 0, 0, 0);
+          cO = __builtin_amdgcn_mfma_f64_16x16x4f64(aOc, bOc, cO, 0, 0, 0);
+          sO = __builtin_amdgcn_mfma_f64_16x16x4f64(aOs, bOs, sO, 0, 0, 0);
+        };
+        for (int k0 = 0; k0 < Ke - 4; k0 += 4) kstep(k0, false);
+        kstep(Ke - 4, true);
+      }
+      uc[j] = cE; us[j] = sE;
+      if (j + 1 < UPW) { uc[j + 1] = cO; us[j + 1] = sO; }
+    }
+    return;
+  }
   if constexpr (TABMODE == 2) {
     // Two units at a time: per K step the eight operands of both are requested together, then four independent MFMAs follow --
     // one exposed LDS round trip per four MFMAs instead of per two (a lone unit, the odd one out, runs two K steps per turn).
@@ -419,6 +486,42 @@ __device__ __forceinline__ void dft_tt_write(const int w, const int lane, const 
   const int n_mt = g.M1 >> 4, n_nt = g.NR >> 4;
   const int n_t1 = n_mt * n_nt;
   const int ST = g.ST, Kc = g.Kc, hh = g.hh, bh = g.bh;
+  if (!(bh & 1)) {
+    // even block height: units j, j + 1 hold the even- and odd-ky half-sums of pair w + (j / 2) NW (dft_stage1); rows y and hh - y
+    const int n_pairs = 2 * n_mt * (g.NRh >> 4);
+#pragma unroll
+    for (int j = 0; j + 1 < UPW; j += 2) {
+      const int pq = w + (j >> 1) * NW;
+      if (pq < n_pairs) {
+        const int t = pq >> 1;
+        const bool im = pq & 1;
+        const int nt = tile_div(t, g.q_mt), mt = t - nt * n_mt;
+        const int y = 16 * nt + l15;
+        if (y <= g.hq) {
+          const int ym = hh - y;
+          double* __restrict__ Th = TT + (im ? Kc * ST : 0);   // real rows, then imaginary rows
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int kx = 16 * mt + l4 + 4 * q;
+            if (kx < Kc) {
+              const double U = uc[j][q] + uc[j + 1][q], V = us[j][q] + us[j + 1][q];
+              const double Um = uc[j][q] - uc[j + 1][q], Vm = us[j + 1][q] - us[j][q];
+              double t1 = im ? U + V : U - V, t2 = im ? U - V : U + V;
+              double t3 = im ? Um + Vm : Um - Vm, t4 = im ? Um - Vm : Um + Vm;
+              if (FOLD_CK && kx != 0 && kx != g.hw) { t1 = 2.0 * t1; t2 = 2.0 * t2; t3 = 2.0 * t3; t4 = 2.0 * t4; }
+              Th[kx * ST + y] = t1;
+              if (y > 0 && y < hh) Th[kx * ST + (bh - y)] = t2;
+              if (ym != y) {
+                Th[kx * ST + ym] = t3;
+                if (ym > 0 && ym < hh) Th[kx * ST + (bh - ym)] = t4;
+              }
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < UPW; ++j) {
     const int u = w + j * NW;
