@@ -184,6 +184,10 @@ struct PropGeom {
   int hq;   // hh / 2: the half-sums are evaluated for y in [0, hq]; hh - y mirrors them
   int NRh;  // ... padded to a multiple of 16
   int Ke;   // terms of a half-sum, padded to a multiple of 4
+  // stage 2 likewise by the parity of kx -- where the width is even, the handle allows it (ProposeArgs::split2) and the pairs of
+  // (x, hw - x) tile slots fit the 16 slots of a workgroup: two slots j, j + 1 of a wave hold x0 = 16 nt + l15 <= hqx and its mirror hw - x0
+  bool split2;
+  int hqx, M1h, Kce;     // hw / 2, (hqx + 1) padded to 16, terms of a half-sum padded to 4
 };
 __device__ __forceinline__ PropGeom prop_geom(const ProposeArgs& a, int bh, int bw) {
   PropGeom g;
@@ -195,6 +199,8 @@ __device__ __forceinline__ PropGeom prop_geom(const ProposeArgs& a, int bh, int 
   g.SX = a.lds_sx; g.ST = a.lds_st;
   g.q_mt = tile_magic(g.M1 >> 4); g.q_mt2 = tile_magic(g.N1 >> 4);
   g.hq = g.hh >> 1; g.NRh = (g.hq + 16) & ~15; g.Ke = (g.hq + 4) & ~3;
+  g.hqx = g.hw >> 1; g.M1h = (g.hqx + 16) & ~15; g.Kce = (g.hqx + 4) & ~3;
+  g.split2 = a.split2 && !(bw & 1) && (g.N1 >> 4) * (g.M1h >> 4) <= 8;
   return g;
 }
 
@@ -547,6 +553,30 @@ __device__ __forceinline__ void dft_tt_write(const int w, const int lane, const 
   }
 }
 
+// Tile slot j of wave w after stage 2: which rows and which column the lane's four values belong to.  Direct form: slot = output
+// tile t = w + j NW of the (N1 / 16) x (M1 / 16) grid, x = 16 nt + l15.  Split form (g.split2): slots j, j + 1 = pair w + (j / 2) NW
+// of the (N1 / 16) x (M1h / 16) grid; the even slot holds x0 = 16 nt + l15 <= hqx, the odd one its mirror hw - x0 (nothing where that is x0 itself).
+struct SlotX { int mt, x; bool ok; };
+__device__ __forceinline__ SlotX slot_x(const int w, const int j, const int NW, const int l15, const PropGeom& g) {
+  SlotX r;
+  const int n_mt2 = g.N1 >> 4;
+  if (g.split2) {
+    const int tp = w + (j >> 1) * NW;
+    const int nt = tile_div(tp, g.q_mt2);
+    r.mt = tp - nt * n_mt2;
+    const int x0 = 16 * nt + l15;
+    r.x = (j & 1) ? g.hw - x0 : x0;
+    r.ok = (w >= 0) && tp < n_mt2 * (g.M1h >> 4) && x0 <= g.hqx && !((j & 1) && g.hw - x0 == x0);
+  } else {
+    const int t = w + j * NW;
+    const int nt = tile_div(t, g.q_mt2);
+    r.mt = t - nt * n_mt2;
+    r.x = 16 * nt + l15;
+    r.ok = (w >= 0) && t < n_mt2 * (g.M1 >> 4) && r.x <= g.hw;
+  }
+  return r;
+}
+
 // ---- stage 2 (MFMA): E = Tr^T Gc, O = Ti^T Gs on x in [0, hw]; results stay in registers -----------
 // tile t of the (N1/16) x (M1/16) output grid goes to wave t mod NW
 // TABMODE as in dft_stage1; 2: tabG = 1-D table of the block width, cos at [m], -sin at [kT1S + m]; T^T carries c_kx
@@ -557,6 +587,62 @@ __device__ __forceinline__ void dft_stage2(const int w, const int lane, const Pr
   const int ST = g.ST, Kc = g.Kc, M1 = g.M1;
   const int n_mt2 = g.N1 >> 4, n_nt2 = M1 >> 4;
   const int n_t2 = n_mt2 * n_nt2;
+  if constexpr (MAXT >= 2) if (g.split2) {
+    // ---- even block width, split by the parity of kx (as dft_stage1 by the parity of ky): E[x] = Ee + Eo, E[hw - x] = Ee - Eo,
+    // O[x] = Oe + Oo, O[hw - x] = -Oe + Oo, the half-sums over kx = 2 m and kx = 2 m + 1 for x in [0, hw / 2] only.  Slot j of the wave
+    // leaves with (E, O) of x0, slot j + 1 with (E, O) of hw - x0 (slot_x): standardise and emit_field treat them as two tiles.
+    const int n_tp = n_mt2 * (g.M1h >> 4);
+    const int Kce = g.Kce, bw = g.bw;
+    const uint32_t n8 = 8u * (uint32_t)bw;
+    const double* __restrict__ G2 = (TABMODE == 1) ? tabG : (TABMODE == 0 ? a.tables + sc.g_off : nullptr);      // [cos: Kc x M1][-sin: Kc x M1]
+#pragma unroll
+    for (int j = 0; j + 1 < MAXT; j += 2) {
+      const int tp = w + (j >> 1) * NW;
+      v4f64 eE = {0.0, 0.0, 0.0, 0.0}, oE = eE, eO = eE, oO = eE;
+      if (tp < n_tp && !(a.dbg & 4)) {
+        const int nt = tile_div(tp, g.q_mt2), mt = tp - nt * n_mt2;
+        const int ycol = 16 * mt + l15, x = 16 * nt + l15;
+        uint32_t mE = 0u, mO = 0u, d8 = 0u;
+        if (TABMODE == 2) {
+          const uint32_t xx = mod_magic((uint32_t)x, (uint32_t)bw, sc.m_bw);
+          mE = 8u * mod_magic((uint32_t)(2 * l4) * xx, (uint32_t)bw, sc.m_bw);
+          mO = 8u * mod_magic((uint32_t)(2 * l4 + 1) * xx, (uint32_t)bw, sc.m_bw);
+          d8 = 8u * mod_magic(8u * xx, (uint32_t)bw, sc.m_bw);
+        }
+        auto kstep = [&](const int k0, const bool last) {
+          int rE = 2 * (k0 + l4), rO = rE + 1;
+          const bool vE = rE < Kc, vO = rO < Kc;
+          if (last) { rE = min(rE, Kc - 1); rO = min(rO, Kc - 1); }
+          double aEr = TT[rE * ST + ycol], aEi = TT[(Kc + rE) * ST + ycol], aOr = TT[rO * ST + ycol], aOi = TT[(Kc + rO) * ST + ycol];
+          if (last) {
+            if (!vE) { aEr = 0.0; aEi = 0.0; }
+            if (!vO) { aOr = 0.0; aOi = 0.0; }
+          }
+          double bEc, bEs, bOc, bOs;
+          if (TABMODE == 2) {
+            const char* tE = (const char*)tabG + mE;
+            const char* tO = (const char*)tabG + mO;
+            bEc = *(const double*)tE; bEs = *(const double*)(tE + 8 * kT1S);
+            bOc = *(const double*)tO; bOs = *(const double*)(tO + 8 * kT1S);
+            mE += d8; mE = min(mE, mE - n8);
+            mO += d8; mO = min(mO, mO - n8);
+          } else {
+            bEc = G2[rE * M1 + x]; bEs = G2[Kc * M1 + rE * M1 + x];
+            bOc = G2[rO * M1 + x]; bOs = G2[Kc * M1 + rO * M1 + x];
+          }
+          eE = __builtin_amdgcn_mfma_f64_16x16x4f64(aEr, bEc, eE, 0, 0, 0);
+          oE = __builtin_amdgcn_mfma_f64_16x16x4f64(aEi, bEs, oE, 0, 0, 0);
+          eO = __builtin_amdgcn_mfma_f64_16x16x4f64(aOr, bOc, eO, 0, 0, 0);
+          oO = __builtin_amdgcn_mfma_f64_16x16x4f64(aOi, bOs, oO, 0, 0, 0);
+        };
+        for (int k0 = 0; k0 < Kce - 4; k0 += 4) kstep(k0, false);
+        kstep(Kce - 4, true);
+      }
+      fe[j] = eE + eO; fo[j] = oE + oO;
+      fe[j + 1] = eE - eO; fo[j + 1] = oO - oE;
+    }
+    return;
+  }
   if constexpr (TABMODE == 2) {
     // two tiles at a time, as in dft_stage1
     struct Tile { const double* a_p; uint32_t m8, d8; bool on; };
@@ -721,10 +807,9 @@ __device__ __forceinline__ double standardise(const int w, const int lane, const
   double part[MAXT];
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
-    const int t = w + j * NW;
-    const int nt = tile_div(t, g.q_mt2), mt = t - nt * n_mt2;
-    const int x = 16 * nt + l15;
-    const bool okx = (w >= 0) && (t < n_t2) && (x <= hw);
+    const SlotX sx = slot_x(w, j, NW, l15, g);
+    const int mt = sx.mt, x = sx.x;
+    const bool okx = sx.ok;
     const bool twox = okx && (x > 0) && (x < hw);
     double p = 0.0;
 #pragma unroll
@@ -740,7 +825,8 @@ __device__ __forceinline__ double standardise(const int w, const int lane, const
     part[j] = p;
   }
   // sum of n^2 (field - mean)^2 -> variance: twice 1 / n for the scaling, once for the mean over the cells
-  const double sd = sqrt(tiles_sum<NW, MAXT>(part, n_t2, red, w, lane) * inv_n * inv_n * inv_n);
+  // (split form: the slots in use are not the first n ones -- an unused slot's partial is zero, every slot is written)
+  const double sd = sqrt(tiles_sum<NW, MAXT>(part, g.split2 ? 32 : n_t2, red, w, lane) * inv_n * inv_n * inv_n);
   return sc.scale / (sd + 1e-12) * inv_n;
 }
 
@@ -762,13 +848,12 @@ __device__ __forceinline__ void emit_field(const int w, const int lane, const Pr
   const double* __restrict__ mask = a.B.masks + sc.mask_off;
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
-    const int t = w + j * NW;
-    const int nt = tile_div(t, g.q_mt2), mt = t - nt * n_mt2;
-    const int x = 16 * nt + l15;
+    const SlotX sx = slot_x(w, j, NW, l15, g);
+    const int mt = sx.mt, x = sx.x;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int y = 16 * mt + l4 + 4 * q;
-      if ((t < n_t2) && (y < bh) && (x <= hw) && !(a.dbg & 8)) {
+      if (sx.ok && (y < bh) && !(a.dbg & 8)) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           if (half == 1 && !(x > 0 && x < hw)) continue;

@@ -1,7 +1,9 @@
 """-m gpu: the strip kernels (chain_strip_kernel.hip: 512-thread workgroups, two chains per CU) against the flux-tile kernels
 (chain_fused_kernel / step_flux_kernel, GSM_STRIP=0) on the same proposals.  Per-cell arithmetic is the same, operation for
 operation (reference gstatsMCMC/MCMC.py:1279-1360, Topography.py:592-600): beds, energies, accept masks, blocks and resampled
-counts must be identical; the loss differs by the order of the window sums only (tolerance 1e-12 relative, stated here)."""
+counts must be identical; the loss differs by the order of the window sums only (tolerance 1e-12 relative, stated here).
+The proposal fields of both runs are made equal with GSM_SPLIT2=0 (handles on the strip kernels otherwise split stage 2 of the
+inverse DFT by the parity of kx, which the one-slot-per-wave flux-tile fused kernel cannot: last-bit differences in the fields)."""
 import os
 import subprocess
 import sys
@@ -35,7 +37,7 @@ np.savez({out!r}, strip=int(eng.strip_active()), loss=loss, acc=acc, blk=blk, be
 
 def _run_child(tmp_path, H, n, state, strip):
     out = str(tmp_path / f"r_{H}_{state}_{strip}.npz")
-    env = dict(os.environ, GSM_STRIP=str(strip))
+    env = dict(os.environ, GSM_STRIP=str(strip), GSM_SPLIT2="0")     # equal fields for both families: the flux-tile fused kernel has no split stage 2
     r = subprocess.run([sys.executable, "-c", _CHILD.format(root=str(ROOT), H=H, n=n, state=state, out=out)], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -94,7 +96,7 @@ def test_strip_kernels_equal_flux_tile_kernels_wide_blocks_on_an_oblong_grid(tmp
     for strip in (1, 0):
         out = str(tmp_path / f"wide_{strip}.npz")
         code = _CHILD_WIDE.format(root=str(ROOT), H=128, W=192, n=80, bw0=20, bw1=110, bh0=20, bh1=50, out=out)
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSM_STRIP=str(strip)), capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSM_STRIP=str(strip), GSM_SPLIT2="0"), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         outs[strip] = np.load(out)
     a, b = outs[1], outs[0]
