@@ -93,13 +93,17 @@ def test_strip_kernels_equal_flux_tile_kernels_wide_blocks_on_an_oblong_grid(tmp
     """Blocks 20 - 110 cells wide and 20 - 50 tall on a 128 x 192 grid, whole-map updates: every strip decomposition up to two
     64-lane column groups (strip::config: 64-, 16-, 32- and 2 x 64-lane strips), H != W, most windows clipped."""
     outs = {}
-    for strip in (1, 0):
-        out = str(tmp_path / f"wide_{strip}.npz")
+    for strip, split2 in ((1, "0"), (0, "0"), (1, "1")):
+        out = str(tmp_path / f"wide_{strip}_{split2}.npz")
         code = _CHILD_WIDE.format(root=str(ROOT), H=128, W=192, n=80, bw0=20, bw1=110, bh0=20, bh1=50, out=out)
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSM_STRIP=str(strip), GSM_SPLIT2="0"), capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSM_STRIP=str(strip), GSM_SPLIT2=split2), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
-        outs[strip] = np.load(out)
-    a, b = outs[1], outs[0]
+        outs[(strip, split2)] = np.load(out)
+    a, b, c = outs[(1, "0")], outs[(0, "0")], outs[(1, "1")]
+    # stage 2 split by the parity of kx (the default on strip handles) against the direct sums: the same chain to rounding
+    assert np.array_equal(c["acc"], a["acc"]) and np.array_equal(c["blk"], a["blk"])
+    np.testing.assert_allclose(c["beds"], a["beds"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(c["loss"], a["loss"], rtol=1e-10)
     assert int(a["strip"]) == 1 and int(b["strip"]) == 0
     widths = set(int(x) for x in a["blk"][..., 3].ravel())
     assert max(widths) > 90 and min(widths) <= 62                 # the two-group 64-lane strips and the one-group ones both ran
