@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
         const int64_t o = noise0 + (int64_t)s * F->noise_stride;
         nz.re = F->noise_re + o; nz.im = F->noise_im + o;
       }
-      coef_items<kST, NOISE, true>(ptid, 0, pg.nrow * pg.ncol, true, pa, q, pg, seed, pa.step0 + s, lds, pa.lds_x_half, nz, mtab);
+      coef_items<kST, NOISE, true>(ptid, 0, pg.nrow * pg.ncol, true, pa, q, pg, seed, pa.step0 + s, lds, pa.lds_x_half, nz, mtab, (pa.parseval && !((q.bh | q.bw) & 1)) ? red2 + 16 : nullptr);
     }
     // Stores of an accepted step must have landed before a later step reads an overlapping window.  They were issued a
     // whole coefficient phase ago; the wait is free, and the barriers that follow order it across the waves.
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kST, 4) void chain_strip_kernel(const FusedArgs fa)
       dft_stage2<kSW, kSMAXT, 2>(wave, ln, pa, q, pg, lds, t1 + 2 * kT1S, fe, fo);
       double gain = 1.0;
       if (dbg & 4096) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else gain = standardise<kSW, kSMAXT>(wave, ln, q, pg, dc0, red2, fe, fo);     // contains a barrier
+      else gain = standardise<kSW, kSMAXT>(wave, ln, q, pg, dc0, red2, fe, fo, (pa.parseval && !((q.bh | q.bw) & 1)) ? red2 + 16 : nullptr);     // contains a barrier; even shapes: variance from the spectrum
       NoiseIn nz{nullptr, nullptr, nullptr};
       if (NOISE) {
         typedef const __attribute__((address_space(4))) FusedArgs* cfa_t;

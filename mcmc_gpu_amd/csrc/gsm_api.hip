@@ -552,7 +552,7 @@ static ProposeArgs make_propose(gsm_handle h, const gsm_rf_params* rf, int n_ste
   p.tiles1_max = h->prop_tiles1; p.tiles2_max = h->prop_tiles;
   // stage 2 split by the parity of kx: on handles whose kernels hold two tile slots per wave (the strip kernels and the stand-alone proposal
   // kernel beside them); GSM_SPLIT2=0 keeps the direct sums (tests/test_gpu_strip.py compares the step kernels of the two families on equal fields)
-  { static int on = -1; if (on < 0) { const char* v = getenv("GSM_SPLIT2"); on = v ? atoi(v) : 1; } p.split2 = (on && strip_for(h)) ? 1 : 0; }
+  { static int on = -1; if (on < 0) { const char* v = getenv("GSM_SPLIT2"); on = v ? atoi(v) : 1; } p.split2 = (on && strip_for(h)) ? 1 : 0; p.parseval = p.split2; }
   return p;
 }
 

@@ -132,6 +132,8 @@ struct ProposeArgs {
   const int32_t* k2_off;   // [n_sizes] offsets into k2tab
   PropScalars* scalars;    // device scratch, n_chains * n_steps records
   int dbg;                 // diagnostics only (GSM_PROPOSE_DBG): bit0 cheap coefficients, bit1 skip stage 1, bit2 skip stage 2
+  int parseval;            // the field's variance from the spectrum (Parseval) instead of from the field: same handles as split2 (the sum's order is that of
+                           // 512-thread workgroups; proposal_device.h: coef_items, standardise)
   int split2;              // stage 2 of even block widths split by the parity of kx where the shape allows it (handles on the strip kernels: every kernel of
                            // such a handle holds two tile slots per wave; the flux-tile fused kernel holds one) -- proposal_device.h: prop_geom
 };

@@ -215,7 +215,8 @@ __device__ __forceinline__ PropGeom prop_geom(const ProposeArgs& a, int bh, int 
 template <int NTH, bool NOISE_IN, bool FOLD_CK = false>
 __device__ __forceinline__ void coef_items(const int t, const int i_lo, const int i_hi, const bool pad, const ProposeArgs& a,
                                            const PropScalars& sc, const PropGeom& g, const uint64_t seed, const int64_t step,
-                                           double* __restrict__ Pr, const int plane, const NoiseIn noise, const double* mt) {
+                                           double* __restrict__ Pr, const int plane, const NoiseIn noise, const double* mt,
+                                           double* pw_red = nullptr) {
   const gsm_rf_params& P = a.rf;
   double* __restrict__ Pi = Pr + plane;
   double* __restrict__ Mr = Pi + plane;
@@ -240,6 +241,7 @@ __device__ __forceinline__ void coef_items(const int t, const int i_lo, const in
     }
   }
   const uint32_t m_nc = sc.m_nc;
+  double pw = 0.0;
   const double* __restrict__ k2tab = a.k2tab + sc.pad;          // this shape's [nrow][ncol] table (pad = its offset)
   for (int i = i_lo + t; i < i_hi && !(a.dbg & 32); i += NTH) {
     const double k2 = k2tab[i];                                 // requested first: lands under the Box-Muller code
@@ -283,6 +285,19 @@ __device__ __forceinline__ void coef_items(const int t, const int i_lo, const in
     Pr[o] = ar + br; Pi[o] = ai + bi;
     Mr[o] = paired ? ar - br : 0.0;
     Mi[o] = paired ? ai - bi : 0.0;
+    // power of the item's entries of the full Hermitian spectrum, the DC term left out: columns 0 < kx < bw / 2 stand for kx and bw - kx
+    // (with FOLD_CK they are stored doubled: |2 X|^2 / 2 = 2 |X|^2 exactly), rows ky and bh - ky are a and b
+    if (pw_red && i != 0) {
+      const bool inner = (kx != 0) && (kx != hw);          // (callers pass pw_red for even shapes only)
+      const double wc = FOLD_CK ? (inner ? 0.5 : 1.0) : (inner ? 2.0 : 1.0);
+      pw += wc * ((ar * ar + ai * ai) + (br * br + bi * bi));
+    }
+  }
+  // Parseval: sum over the cells of (n (field - mean))^2 = n * sum_{k != 0} |X_k|^2 -- the standardisation's variance without a pass over the
+  // field (standardise).  Partial of each wave -> pw_red[wave]; read after the barrier that ends the coefficient phase.
+  if (pw_red) {
+    const double ws = dev::wave64_sum(pw);
+    if ((t & 63) == 0) pw_red[t >> 6] = ws;
   }
 }
 
@@ -798,12 +813,29 @@ __device__ __forceinline__ double tiles_sum(const double (&part)[MAXT], const in
 // the deviations are still squared about the mean (fields whose spectrum is all but DC have mean^2 >> variance).
 template <int NW, int MAXT>
 __device__ __forceinline__ double standardise(const int w, const int lane, const PropScalars& sc, const PropGeom& g, const double dc,
-                                              double* red, v4f64 (&fe)[MAXT], v4f64 (&fo)[MAXT]) {
+                                              double* red, v4f64 (&fe)[MAXT], v4f64 (&fo)[MAXT], const double* pw_red = nullptr) {
   const int l15 = lane & 15, l4 = lane >> 4;
   const int bh = g.bh, hw = g.hw;
   const int n_mt2 = g.N1 >> 4, n_t2 = n_mt2 * (g.M1 >> 4);
   const int ncell = bh * g.bw;
   const double inv_n = 1.0 / (double)ncell;
+  if (pw_red) {
+    // the variance comes from the spectrum (coef_items: pw_red[0 .. NW) = the waves' partials of sum_{k != 0} |X_k|^2): only the deviations
+    // are formed here; the barrier stays (T^T -> field tile: every wave is past its stage-2 reads)
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double e = fe[j][q], o = fo[j][q];
+        fe[j][q] = (e + o) - dc; fo[j][q] = (e - o) - dc;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    double S = pw_red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) S += pw_red[i];
+    const double sd = sqrt(S * inv_n * inv_n);      // field = ifft / n: sum (field - mean)^2 = S / n, variance S / n^2
+    return sc.scale / (sd + 1e-12) * inv_n;
+  }
   double part[MAXT];
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
@@ -909,7 +941,10 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
   double* mt = red + 32;                      // [kMathTabDoubles] math_tables.h
   for (int i = tid; i < kMathTabDoubles; i += NT) mt[i] = a.mathtab[i];
   __syncthreads();
-  coef_items<NT, NOISE_IN>(tid, 0, g.nrow * g.ncol, true, a, sc, g, seed, step, plds, a.lds_x_half, noise, mt);
+  // even shapes (every table of the reference) on handles of the strip family: red[16 .. 24) is free beside tiles_sum's 16 slots.  Odd sizes keep the
+  // pass over the field: the half-plane's last column / row is then no self-conjugate entry and the stages weight it by convention
+  double* pw_red = (a.parseval && NW == 8 && !((sc.bh | sc.bw) & 1)) ? red + 16 : nullptr;
+  coef_items<NT, NOISE_IN>(tid, 0, g.nrow * g.ncol, true, a, sc, g, seed, step, plds, a.lds_x_half, noise, mt, pw_red);
   __syncthreads();
   // Mean of the field (MCMC.py:248 subtracts it): every non-DC term of the inverse DFT sums to zero over the block, so
   // mean = X[0][0] / (bh bw) with X[0][0] = Pr[0] (real: its own conjugate partner).  Read before T^T overlays the plane.
@@ -922,7 +957,7 @@ __device__ __forceinline__ void propose_field(const int tid, const ProposeArgs& 
   v4f64 fe[MAXT], fo[MAXT];
   dft_stage2<NW, MAXT, false>(wave, lane, a, sc, g, plds, nullptr, fe, fo);
   double mreg[MAXT][8];
-  const double gain = standardise<NW, MAXT>(wave, lane, sc, g, dc, red, fe, fo);
+  const double gain = standardise<NW, MAXT>(wave, lane, sc, g, dc, red, fe, fo, pw_red);
   const bool with_nugget = NOISE_IN ? (noise.nug != nullptr) : (a.rf.nugget_max > 0.0);
   emit_field<NW, MAXT, false>(wave, lane, a, sc, g, fe, fo, mreg, gain, with_nugget, out, omap);
   if (with_nugget) {
